@@ -1,0 +1,53 @@
+/* nae_dsp_spec.h — numeric constants of the builder-defined DSP nodes (K7 tempo/pitch, K8 spectrum).
+ *
+ * The reference has NO code for the FFT spectrum node (FFTW is only a declared dependency,
+ * /root/reference/xmake.lua:15,33) and delegates tempo/pitch to SoundTouch 2.3.2, which is not in the
+ * tree (/root/reference/src/processor/audio-velocity.cpp:286,369-385).  BASELINE.json:north_star prescribes
+ * "hand-written radix-2/4 LDS FFTs plus phase-vocoder analysis/resynthesis", so the algorithm is specified
+ * HERE, once, and implemented twice: by the HIP kernels (nodey-audio-editor_amd/csrc) and, independently,
+ * by the CPU oracle (oracle/).  Only constants live in this header — no shared code.
+ *
+ * The full algorithm text is DESIGN.md §3 ("K7/K8 specification").
+ */
+#ifndef NAE_DSP_SPEC_H
+#define NAE_DSP_SPEC_H
+
+/* STFT geometry (BASELINE.json configs[2]: "1024-pt FFT, 75 % overlap") */
+#define NAE_FFT_N 1024          /* real frame length                       */
+#define NAE_FFT_NC 512          /* packed complex length (N/2)             */
+#define NAE_FFT_BINS 513        /* r2c bins k = 0..N/2                     */
+#define NAE_HOP 256             /* synthesis hop / spectrum hop (N/4)      */
+#define NAE_OLA_GAIN (2.0f / 3.0f) /* 1 / sum_t hann^2 at hop N/4 = 1/1.5  */
+
+/* atan2 in turns: atan(t)/(2 pi) = t * Q(t*t), t in [0,1]; degree-6 minimax, max err 5.5e-8 turn.
+ * Horner with fused multiply-add, coefficient order c0 (constant) .. c6.                                   */
+#define NAE_ATAN_C0 1.591543257e-01f
+#define NAE_ATAN_C1 -5.302623659e-02f
+#define NAE_ATAN_C2 3.152511641e-02f
+#define NAE_ATAN_C3 -2.106151544e-02f
+#define NAE_ATAN_C4 1.267249603e-02f
+#define NAE_ATAN_C5 -5.348273553e-03f
+#define NAE_ATAN_C6 1.084129326e-03f
+
+/* 1/sqrt(2) rounded to f32, used by the 8-point butterflies */
+#define NAE_SQRT1_2 0.70710678118654752440f
+
+/* phase vocoder fixed-point formats */
+#define NAE_HA_FRAC_BITS 24     /* analysis hop Ha = Hs * tempo, Q39.24                      */
+#define NAE_R_FRAC_BITS 24      /* synthesis/analysis hop ratio Hs/d_t, Q8.24                 */
+#define NAE_TEMPO_MIN (1.0 / 64.0)   /* Ha >= 4 samples  */
+#define NAE_TEMPO_MAX 16.0
+
+/* resampler (rate transposer): 16-tap Kaiser-windowed sinc, 128 phases, linear phase interpolation */
+#define NAE_RS_TAPS 16
+#define NAE_RS_PHASES 128
+#define NAE_RS_KAISER_BETA 8.0
+#define NAE_RS_CUTOFF 0.94      /* fraction of the narrower Nyquist */
+#define NAE_RATE_MIN (1.0 / 16.0)
+#define NAE_RATE_MAX 16.0
+
+/* x86 "integer indefinite" produced by cvttss2si on overflow/NaN: what the reference's
+ * truncating float->int32 gain path yields out of range (audio-vol.cpp:98, int32_t case). */
+#define NAE_X86_INT_INDEFINITE (-2147483647 - 1)
+
+#endif
