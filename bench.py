@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json's headline metric on MI355X.
+
+One "step" = one pass of the 4-node graph  input -> mix(2) -> pitch(+3 semitones) -> FFT spectrum  over every
+stream resident on this GPU (BASELINE.json configs[4] / SURVEY.md §8d C5: 1024 independent 48 kHz stereo f32
+streams of 10 s, the second mix input shared by all streams).  Streams shard across GPUs with no data-path
+collective (weak scaling: every rank owns `--streams` streams); the shared source buffer is broadcast once over
+RCCL at setup.  Inputs are resident in HBM before the timed region.
+
+    python bench.py                       # 1 GPU, defaults
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md §4 for the fields).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
+SEMITONES = 3.0
+BINS = 513
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--streams", type=int, default=1024, help="streams per GPU (C5: 1024)")
+    ap.add_argument("--seconds", type=float, default=10.0, help="length of every stream at 48 kHz (C5: 10 s)")
+    ap.add_argument("--cpu-streams", type=int, default=48, help="streams the CPU-oracle baseline is timed on")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    torch = None
+    if world > 1 or a.gpus > 1:
+        # torch first: its bundled libamdhip64.so.7 is then the one HIP runtime of the process (same soname as
+        # /opt/rocm's, so libnae_gpu.so binds to it and device pointers are interchangeable)
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+        assert world == a.gpus, f"launched {world} ranks for --gpus {a.gpus}"
+
+    import numpy as np
+    import naeload
+    nae = naeload.load()
+    ctx = nae.Context(local_rank)
+    n_streams, S = a.streams, int(round(a.seconds * 48000))
+    pitch = 2.0 ** (SEMITONES / 12.0)
+    pl = ctx.stretch_plan(1.0, pitch, S)
+    F = ctx.spectrum_frames(pl.out_len)
+
+    # ---- buffers (all HBM-resident before timing)
+    d_a = ctx.empty(n_streams * S * 2)
+    d_mix = ctx.empty(n_streams * S * 2)
+    d_pitch = ctx.empty(n_streams * pl.out_len * 2)
+    d_spec = ctx.empty(n_streams * F * 2 * BINS)
+    first_stream = rank * n_streams                      # stream s of the job lives on rank s // n_streams
+    ctx.fill_uniform(d_a.ptr, S * 2, S * 2, n_streams, first_stream, 0)
+    if dist is not None:
+        # shared second mix input: generated on rank 0, broadcast over RCCL/xGMI (the only collective)
+        t_b = torch.empty(S * 2, dtype=torch.float32, device=f"cuda:{local_rank}")
+        if rank == 0:
+            ctx.fill_uniform(t_b.data_ptr(), S * 2, 0, 1, 0, 1)
+            ctx.sync()
+        dist.broadcast(t_b, src=0)
+        torch.cuda.synchronize()
+        b_ptr = t_b.data_ptr()
+    else:
+        d_b = ctx.empty(S * 2)
+        ctx.fill_uniform(d_b.ptr, S * 2, 0, 1, 0, 1)
+        b_ptr = d_b.ptr
+    ctx.sync()
+
+    g = nae.Graph4()
+    g.in_a = nae.Sig.interleaved(d_a.ptr, S, 2)
+    g.in_b = nae.Sig.interleaved(b_ptr, S, 2, shared=True)
+    g.vol_a = g.vol_b = 0.5
+    g.mix_out = nae.Sig.planar(d_mix.ptr, S, 2)
+    g.rate, g.pitch = 1.0, pitch
+    g.pitch_out = nae.Sig.interleaved(d_pitch.ptr, pl.out_len, 2)
+    g.spec_out, g.spec_stream_stride = d_spec.ptr, F * 2 * BINS
+    g.S, g.n_streams = S, n_streams
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        ctx.graph4(g)
+    barrier()
+    if not a.no_kernel_timing:
+        ctx.prof_reset()
+        ctx.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        ctx.graph4(g)
+    ctx.sync()
+    if dist is not None:
+        torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    kernels = {}
+    if not a.no_kernel_timing:
+        ctx.prof_enable(False)
+        kernels = ctx.prof_report()
+    if dist is not None:
+        t_el = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
+        elapsed = float(t_el.item())
+        dist.barrier()
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    frames_per_step = world * n_streams * S
+    value = frames_per_step * a.steps / elapsed
+
+    # ---- roofline of the dominant kernel: algorithmic (compulsory) bytes of that launch / its mean duration
+    sf = n_streams * S                                   # sample-frames one launch covers on this GPU
+    mid_ratio = pl.mid_len / S
+    alg_bytes = {                                        # per launch; DESIGN.md §4 derives each figure
+        "amix_i2p_kernel": 24.0 * sf,                    # 2 x 8 B in + 8 B out            (mix n=2 = 24 B)
+        "pv_phase_kernel": 8.0 * sf,                     # re-read of the input (pass 1); output negligible
+        "pv_scan_kernel": 0.0,
+        "pv_synth_kernel": 8.0 * sf + 8.0 * sf * mid_ratio,   # input once + stretched signal once
+        "resample_kernel": 8.0 * sf * mid_ratio + 8.0 * sf,   # stretched signal once + output once
+        "spectrum_kernel": 8.0 * sf + 2 * BINS * 4.0 * n_streams * F,   # 24.03 B per sample-frame
+    }
+    roofline = None
+    kern_report = {}
+    for name, (ms, cnt) in kernels.items():
+        avg = ms / max(cnt, 1)
+        gbs = alg_bytes.get(name, 0.0) / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
+        kern_report[name] = {"avg_ms": round(avg, 4), "launches": int(cnt), "alg_GBps": round(gbs, 1),
+                             "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")    # written from the rocprofv3 --pmc passes
+    tdata = json.load(open(tpath)) if os.path.exists(tpath) else {}
+    if kernels:
+        dom = max(kernels, key=lambda k: kernels[k][0])
+        avg_s = kernels[dom][0] / max(kernels[dom][1], 1) * 1e-3
+        ach = alg_bytes.get(dom, 0.0) / avg_s / 1e9
+        if dom in tdata and tdata[dom].get("sample_frames"):
+            traffic = tdata[dom]["hbm_bytes_per_launch"] * sf / tdata[dom]["sample_frames"]
+        roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "avg_launch_ms": round(avg_s * 1e3, 4), "alg_bytes_per_launch": alg_bytes.get(dom, 0.0),
+                    "note": "K7 is VALU/LDS-bound (FFT + atan2/sincos per bin), not HBM-bound; see DESIGN.md §4"}
+    chain_gbs = 64.03 * value / world / 1e9              # 24 + 16 + 24.03 B per sample-frame, per GPU
+
+    out = {
+        "metric": "stereo f32 sample-frames/s through the 4-node graph input->mix(2)->pitch->FFT-spectrum @48 kHz",
+        "value": value, "unit": "sample-frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "C5 (BASELINE.json configs[4]): independent 48 kHz stereo f32 streams through "
+                               "input->mix(2)->pitch(+3 semitones, phase vocoder N=1024 hop=256)->spectrum(N=1024 hop=256)",
+                   "streams_per_gpu": n_streams, "seconds_per_stream": a.seconds, "sample_frames_per_stream": S,
+                   "shared_second_input": True, "parallelism": f"streams sharded over {world} GPU(s), no data-path collective",
+                   "device": ctx.name()},
+        "roofline": roofline,
+        "chain": {"alg_bytes_per_sample_frame": 64.03, "alg_GBps_per_gpu": round(chain_gbs, 1),
+                  "frac_hbm_peak": round(chain_gbs / HBM_PEAK_GBS, 4)},
+        "kernels": kern_report,
+    }
+
+    # ---- CPU baseline (reported, not the target): the oracle's restatement of the same graph, 1 thread
+    if not a.no_cpu_baseline and world == 1:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import orc                                          # oracle: allowed here only as the timed checker
+        k = max(1, min(a.cpu_streams, n_streams))
+        b = orc.fill_uniform(S * 2, orc.stream_seed(0, 1))
+        ins = [orc.fill_uniform(S * 2, orc.stream_seed(s, 0)) for s in range(k)]
+        tc0 = time.perf_counter()
+        refs = []
+        for s in range(k):
+            x = ins[s]
+            L, R = orc.amix([x[0::2], b[0::2]], [x[1::2], b[1::2]], [0.5, 0.5])
+            p_out = orc.stretch(orc.interleave([L, R]), 2, 1.0, pitch)
+            sp = orc.spectrum(p_out, 2)
+            if s == 0:
+                refs = [p_out, sp]
+        tc1 = time.perf_counter()
+        out["cpu_baseline"] = {"value": k * S / (tc1 - tc0), "unit": "sample-frames/s", "cores": 1, "kind": "port",
+                               "sample": f"{k} of the {n_streams} streams ({a.seconds:g} s each), same 4-node graph, "
+                                         f"oracle C restatement (-O3, no fast-math), 1 thread as the reference's runner "
+                                         f"is single-threaded (src/infra/runner.cpp:65-69); host has {os.cpu_count()} cpus",
+                               "seconds": round(tc1 - tc0, 2)}
+        # parity of this very run: stream 0 of the GPU result against the oracle
+        gp = np.empty(pl.out_len * 2, np.float32)
+        gs = np.empty(F * 2 * BINS, np.float32)
+        ctx._ck(ctx.lib.nae_memcpy_d2h(ctx.h, gp.ctypes.data, d_pitch.ptr, gp.nbytes))
+        ctx._ck(ctx.lib.nae_memcpy_d2h(ctx.h, gs.ctypes.data, d_spec.ptr, gs.nbytes))
+        ctx.sync()
+        rr = lambda x, y: float(np.sqrt(np.mean((x.astype(np.float64) - y) ** 2)) / np.sqrt(np.mean(y.astype(np.float64) ** 2)))
+        out["rms_err_vs_oracle"] = {"pitch_out": rr(gp, refs[0]), "spectrum_out": rr(gs, refs[1].reshape(-1)), "tolerance": 1e-4}
+    print(json.dumps(out))
+    sys.stdout.flush()
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,225 @@
+/* nae_gpu.h — C-ABI of the MI355X (gfx950) audio-DSP hot path.
+ *
+ * Drop-in boundary for the per-node sample transforms of Stehsaer/nodey-audio-editor
+ * (reference paths below are relative to /root/reference).  Every entry point replaces one CPU inner loop
+ * that today runs inside a `processor::*::process_payload` fiber (include/infra/processor.hpp:108-113);
+ * the adapter classes in nodey-audio-editor_amd/host/ call these from the same place.
+ *
+ * Conventions
+ *  - plain C, no exceptions cross the ABI: every function returns NAE_OK (0) or a negative nae_status;
+ *    nae_last_error(ctx) gives the text.  The adapter converts non-zero into
+ *    infra::Processor::Runtime_error (include/infra/processor.hpp:64-77).
+ *  - all sample pointers are DEVICE pointers (hipMalloc / nae_malloc) unless the name ends in _host.
+ *    "plane pointer arrays" (const T* const*) are HOST arrays whose elements are device pointers — the
+ *    same shape as AVFrame::data (audio-vol.cpp:185-186).
+ *  - every call only ENQUEUES work on the context's HIP stream and returns; nae_sync() blocks,
+ *    nae_poll() never blocks (a Boost fiber polls it and yields: src/infra/runner.cpp:65-83 runs every node
+ *    on ONE OS thread, so a blocking wait would stall the whole graph).
+ *  - sample formats use FFmpeg's AVSampleFormat numbering so frame->format passes through unchanged.
+ */
+#ifndef NAE_GPU_H
+#define NAE_GPU_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NAE_ABI_VERSION 1
+
+typedef enum nae_status {
+    NAE_OK = 0,
+    NAE_ERR_INVALID = -1,     /* bad argument (null pointer, channel count not 1/2 where the reference rejects it, ...) */
+    NAE_ERR_UNSUPPORTED = -2, /* sample format / parameter outside the reference's envelope            */
+    NAE_ERR_HIP = -3,         /* HIP runtime error; nae_last_error has hipGetErrorString               */
+    NAE_ERR_NOMEM = -4,
+    NAE_ERR_STATE = -5        /* call order violation on a stateful handle                            */
+} nae_status;
+
+/* == AVSampleFormat (libavutil/samplefmt.h) for the formats audio-vol.cpp:188-244 and
+ * audio-velocity.cpp:160-229 accept */
+typedef enum nae_fmt {
+    NAE_FMT_S16 = 1, NAE_FMT_S32 = 2, NAE_FMT_FLT = 3, NAE_FMT_S16P = 6, NAE_FMT_S32P = 7, NAE_FMT_FLTP = 8
+} nae_fmt;
+
+typedef struct nae_ctx nae_ctx;
+typedef struct nae_event nae_event;
+typedef struct nae_stretch nae_stretch;
+typedef struct nae_spectrum nae_spectrum;
+
+/* ------------------------------------------------------------------ context / plumbing */
+int nae_abi_version(void);
+int nae_device_count(void);
+int nae_ctx_create(int device, nae_ctx** out);          /* one per GPU (one per process in the sharded bench) */
+int nae_ctx_destroy(nae_ctx* ctx);
+int nae_ctx_set_stream(nae_ctx* ctx, void* hip_stream); /* borrow a hipStream_t (e.g. torch's current stream) */
+void* nae_ctx_stream(nae_ctx* ctx);
+int nae_sync(nae_ctx* ctx);                             /* hipStreamSynchronize                               */
+int nae_poll(nae_ctx* ctx);                             /* 1 = idle, 0 = work pending, <0 = error; never blocks */
+const char* nae_last_error(nae_ctx* ctx);
+const char* nae_device_name(nae_ctx* ctx);
+
+int nae_malloc(nae_ctx* ctx, size_t bytes, void** dptr);
+int nae_free(nae_ctx* ctx, void* dptr);
+int nae_memcpy_h2d(nae_ctx* ctx, void* dst, const void* src_host, size_t bytes); /* async on the ctx stream */
+int nae_memcpy_d2h(nae_ctx* ctx, void* dst_host, const void* src, size_t bytes); /* async on the ctx stream */
+int nae_memcpy_d2d(nae_ctx* ctx, void* dst, const void* src, size_t bytes);
+int nae_memset(nae_ctx* ctx, void* dst, int value, size_t bytes);
+
+int nae_event_create(nae_ctx* ctx, nae_event** ev);
+int nae_event_record(nae_ctx* ctx, nae_event* ev);      /* on the ctx stream */
+int nae_event_elapsed_ms(nae_event* start, nae_event* stop, float* ms); /* synchronises on `stop` */
+int nae_event_destroy(nae_event* ev);
+
+/* per-kernel timing: when enabled every kernel launch is bracketed by two hipEvents on the ctx stream.
+ * nae_prof_get(index) returns the number of distinct kernels seen; call with index = -1 to get only the count. */
+int nae_prof_enable(nae_ctx* ctx, int on);
+int nae_prof_reset(nae_ctx* ctx);
+int nae_prof_get(nae_ctx* ctx, int index, char* name, size_t name_cap, double* total_ms, uint64_t* launches);
+
+/* synthetic input: dst[s*stream_stride + i] = uniform[-1,1) from splitmix64 with
+ * seed(s) = 0x9E3779B97F4A7C15*(1 + first_stream + s) + input_index, i < n_per_stream.  Benchmark/test utility. */
+int nae_fill_uniform_f32(nae_ctx* ctx, float* dst, size_t n_per_stream, size_t stream_stride, size_t n_streams,
+                         uint64_t first_stream, uint64_t input_index);
+
+/* ------------------------------------------------------------------ batched signal view
+ * element (stream s, channel c, sample-frame i) lives at base[s*stream_stride + c*chan_stride + i*frame_stride]
+ * (strides in ELEMENTS).  interleaved [S][ch]: chan_stride 1, frame_stride ch;  planar [ch][S]: chan_stride S,
+ * frame_stride 1.  stream_stride 0 = every stream reads the same buffer (a shared source). */
+typedef struct nae_sig {
+    void* base;
+    size_t stream_stride;
+    size_t chan_stride;
+    size_t frame_stride;
+} nae_sig;
+
+/* ------------------------------------------------------------------ K1 gain
+ * replaces change_volume<T>, src/processor/audio-vol.cpp:75-100 (dispatch :188-244).
+ * dst[p][i] = T(float(src[p][i]) * volume); f32: one IEEE multiply; s16/s32: truncation toward zero,
+ * no clamp, x86 out-of-range result (0x80000000, then modular narrowing for s16).  src == dst allowed. */
+int nae_gain_f32(nae_ctx* ctx, const float* const* src_planes, float* const* dst_planes, int planes,
+                 size_t elems, float volume);
+int nae_gain_s16(nae_ctx* ctx, const int16_t* const* src_planes, int16_t* const* dst_planes, int planes,
+                 size_t elems, float volume);
+int nae_gain_s32(nae_ctx* ctx, const int32_t* const* src_planes, int32_t* const* dst_planes, int planes,
+                 size_t elems, float volume);
+/* whole-frame entry mirroring the format switch at audio-vol.cpp:184-244: `planes` has 1 pointer for packed
+ * formats and `ch` pointers for planar ones; ch must be 1 or 2 (:177-182) */
+int nae_gain_frame(nae_ctx* ctx, int fmt, const void* const* src_planes, void* const* dst_planes, size_t S,
+                   int ch, float volume);
+
+/* ------------------------------------------------------------------ K2 split / merge
+ * deinterleave replaces swr_convert FLT->FLTP at equal rate/layout (audio-amix.cpp:263-269,
+ * audio-bimix.cpp:259-265); interleave replaces audio-velocity.cpp:169-180. Bit copies. */
+int nae_deinterleave_f32(nae_ctx* ctx, const float* src, float* const* dst_planes, size_t S, int ch);
+int nae_interleave_f32(nae_ctx* ctx, const float* const* src_planes, float* dst, size_t S, int ch);
+/* batched: n_streams x ch x S through nae_sig views (configs[1]: 1000 buffers of 4096) */
+int nae_copy_sig_f32(nae_ctx* ctx, const nae_sig* src, const nae_sig* dst, size_t S, int ch, size_t n_streams);
+/* fused split -> gain -> merge on interleaved stereo (the three nodes of configs[1] in one pass) */
+int nae_gain_sig_f32(nae_ctx* ctx, const nae_sig* src, const nae_sig* dst, size_t S, int ch, size_t n_streams,
+                     float volume);
+
+/* ------------------------------------------------------------------ K3 N-input mix
+ * replaces the loop at audio-amix.cpp:293-307: L[j] = (((0 + a0L[j]*v0) + a1L[j]*v1) + ...), same for R;
+ * multiply and add are never fused.  1 <= n <= 16 (audio-amix.cpp:342). */
+int nae_amix_f32(nae_ctx* ctx, const float* const* inL, const float* const* inR, const float* vol_host, int n,
+                 float* outL, float* outR, size_t S);
+/* batched over streams; inputs may be interleaved (the node's swr FLT->FLTP step is folded in) or planar */
+int nae_amix_sig_f32(nae_ctx* ctx, const nae_sig* inputs, const float* vol_host, int n, const nae_sig* out,
+                     size_t S, size_t n_streams);
+
+/* ------------------------------------------------------------------ K4 channel mix v1
+ * replaces audio-bimix.cpp:310-317: outL = (ll/2 + lr/2)*(1-bias), outR = (rl/2 + rr/2)*(1+bias) */
+int nae_bimix_f32(nae_ctx* ctx, const float* ll, const float* lr, const float* rl, const float* rr, float bias,
+                  float* outL, float* outR, size_t S);
+
+/* ------------------------------------------------------------------ K5 channel mix v2
+ * downmix replaces audio-bimix.cpp:624-627,717-720 (mono = (l+r)*0.5); interleave replaces :797-803,
+ * :833-850 and the single-sided tails :736-742,:759-765 (later == NULL, aligned == 0). */
+int nae_bimix2_downmix_f32(nae_ctx* ctx, const float* l, const float* r, float* mono, size_t S);
+int nae_bimix2_interleave_f32(nae_ctx* ctx, float* dst, const float* earlier, const float* later,
+                              size_t unaligned, size_t aligned, int earlier_offset);
+
+/* ------------------------------------------------------------------ K6 any format -> interleaved f32
+ * replaces extract_samples_interleaved, audio-velocity.cpp:150-232 (divisors 32768.0f / 32767 /
+ * 2147483648.0f / (double)2147483647 kept literally).  NAE_ERR_UNSUPPORTED where the reference throws. */
+int nae_to_f32_interleaved(nae_ctx* ctx, int fmt, const void* const* planes, size_t S, int ch, float* dst);
+
+/* sink-side clamp, audio-io.cpp:617-618 */
+int nae_clamp_f32(nae_ctx* ctx, float* data, size_t n);
+
+/* ------------------------------------------------------------------ K7 tempo / pitch
+ * replaces the SoundTouch object driven by soundtouch_process_payload, audio-velocity.cpp:265-443
+ * (setSampleRate/setChannels/setRate/setPitch :381-385, putSamples :403, numSamples :399,414,419,
+ * receiveSamples :298, flush :427).  Algorithm: phase vocoder (N=1024, hop 256) + windowed-sinc rate
+ * transposer, DESIGN.md §3 — NOT SoundTouch's WSOLA; parity vs SoundTouch is unpinned.
+ * Velocity_modifier passes (rate = velocity, pitch = keep_pitch ? 1/velocity : 1) (:445-460);
+ * Pitch_modifier passes (rate = 1, pitch = 2^(semitones/12)) (:462-477). */
+typedef struct nae_stretch_plan {
+    int pv_on, rs_on;
+    double tempo_eff, rate_eff;
+    int64_t ha_q24;
+    int32_t d0;
+    uint32_t r_q24[2];
+    uint64_t step_q32;
+    size_t out_len, mid_len, frames;
+} nae_stretch_plan;
+int nae_stretch_plan_make(double rate, double pitch, size_t in_len, nae_stretch_plan* plan);
+
+/* block form: n_streams independent signals of in_len sample-frames each; dst receives plan.out_len frames.
+ * Workspace is owned by the context and grown on demand (never freed between calls). */
+int nae_stretch_block_f32(nae_ctx* ctx, double rate, double pitch, const nae_sig* src, size_t in_len, int ch,
+                          size_t n_streams, const nae_sig* dst);
+/* debugging tap used by the parity tests: synthesis phase (Q0.32) in front of every PV tile,
+ * dst_host[n_streams][ch][n_tiles][513] int32; returns n_tiles through *n_tiles and the tile length in frames */
+int nae_debug_pv_tile_phase(nae_ctx* ctx, double rate, double pitch, const nae_sig* src, size_t in_len, int ch,
+                            size_t n_streams, int32_t* dst_host, size_t dst_capacity, size_t* n_tiles,
+                            size_t* tile_frames);
+
+/* SoundTouch-shaped streaming handle (interleaved f32, device pointers) */
+int nae_stretch_create(nae_ctx* ctx, int sample_rate, int channels, float rate, float pitch, nae_stretch** h);
+int nae_stretch_put(nae_stretch* h, const float* interleaved, size_t S);
+int nae_stretch_put_host(nae_stretch* h, const float* interleaved_host, size_t S);
+int nae_stretch_flush(nae_stretch* h);
+size_t nae_stretch_available(nae_stretch* h);                          /* == SoundTouch::numSamples()    */
+int nae_stretch_receive(nae_stretch* h, float* dst, size_t max_frames, size_t* got);
+int nae_stretch_receive_host(nae_stretch* h, float* dst_host, size_t max_frames, size_t* got);
+int nae_stretch_destroy(nae_stretch* h);
+
+/* ------------------------------------------------------------------ K8 FFT spectrum
+ * no reference code (FFTW declared at xmake.lua:15,33, never called).  Spec: per channel, periodic-Hann
+ * windowed 1024-point forward r2c DFT every 256 sample-frames, un-normalised (FFTW convention),
+ * |X[k]| for k = 0..512.  frames = T < 1024 ? 0 : (T-1024)/256 + 1.
+ * dst element (s, frame f, channel c, bin k) at dst_base[s*dst_stream_stride + (f*ch + c)*513 + k]. */
+size_t nae_spectrum_frames(size_t T);
+int nae_spectrum_block_f32(nae_ctx* ctx, const nae_sig* src, size_t T, int ch, size_t n_streams, float* dst,
+                           size_t dst_stream_stride);
+/* streaming handle: put interleaved samples, receive whole frames [ch][513] */
+int nae_spectrum_create(nae_ctx* ctx, int n_fft, int hop, int channels, nae_spectrum** h);
+int nae_spectrum_put(nae_spectrum* h, const float* interleaved, size_t S);
+size_t nae_spectrum_available(nae_spectrum* h);                         /* whole frames ready */
+int nae_spectrum_receive(nae_spectrum* h, float* dst, size_t max_frames, size_t* got);
+int nae_spectrum_destroy(nae_spectrum* h);
+
+/* ------------------------------------------------------------------ the 4-node graph of BASELINE.json
+ * input -> mix(2) -> pitch -> FFT spectrum, one launch sequence over n_streams independent streams.
+ * Each node still materialises its output in HBM (the plugin contract: one Audio_stream per link,
+ * src/infra/runner.cpp:35-50), so the intermediate buffers are caller-provided. */
+typedef struct nae_graph4 {
+    nae_sig in_a, in_b;       /* two mix inputs, interleaved stereo f32; in_b.stream_stride may be 0 (shared) */
+    float vol_a, vol_b;
+    nae_sig mix_out;          /* planar stereo (the amix node emits FLTP, audio-amix.cpp:198)                 */
+    double rate, pitch;       /* pitch node parameters                                                         */
+    nae_sig pitch_out;        /* interleaved stereo (construct_audio_frame_float emits FLT, audio-velocity.cpp:247) */
+    float* spec_out;          /* [n_streams][frames][2][513]                                                  */
+    size_t spec_stream_stride;
+    size_t S;                 /* sample-frames per stream                                                      */
+    size_t n_streams;
+} nae_graph4;
+int nae_graph4_run(nae_ctx* ctx, const nae_graph4* g);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

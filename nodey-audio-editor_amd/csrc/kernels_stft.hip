@@ -1,0 +1,475 @@
+// kernels_stft.hip — K8 FFT spectrum and K7 tempo/pitch (phase vocoder + rate transposer) for gfx950.
+//
+// Mapping (MI355X: 256 CUs x 4 SIMD, wave64, 160 KiB LDS/CU):
+//   * one wavefront = one (stream, channel, tile of frames); a 512-thread workgroup is 8 independent waves
+//     that only share the read-only Hann / split-twiddle tables in LDS (one __syncthreads after the table
+//     fill, none afterwards).
+//   * per wave LDS: 4.5 KiB FFT scratch + 4 KiB overlap-add ring  -> 2 workgroups (16 waves) per CU.
+//   * the phase accumulator is Q0.32 integer, so the time recurrence of the vocoder is an exact prefix sum:
+//     pass 1 (pv_phase_kernel) reduces each tile's phase increments, pass 2 (pv_scan_kernel) scans tiles,
+//     pass 3 (pv_synth_kernel) recomputes the tile with the right starting phase and overlap-adds in LDS.
+//     HBM traffic stays at the algorithmic 4 B in + 4 B out per sample per channel (+ one re-read in pass 1).
+//
+// Replaces: SoundTouch behind /root/reference/src/processor/audio-velocity.cpp:369-428 (K7; algorithm differs,
+// see DESIGN.md §3) and the FFTW-based spectrum the reference declares but never implements (K8).
+#include "nae_internal.h"
+#include "stft_device.h"
+
+namespace nae {
+
+constexpr int kWaves = 8;                        // waves per workgroup
+constexpr int kThreads = kWaves * 64;
+constexpr int kT1024Pad = kPhasePad;             // 513 entries, padded to 520
+constexpr size_t kLdsTables = NAE_FFT_N * sizeof(float) + kT1024Pad * sizeof(cf);
+constexpr size_t kLdsPerWaveSpec = kScratchCf * sizeof(cf);
+constexpr size_t kLdsPerWavePv = kScratchCf * sizeof(cf) + kRingFloats * sizeof(float);
+
+struct Tables { const cf* w512; const cf* t1024; const float* hann; };
+
+struct LdsLayout {
+    float* hann;
+    cf* t1024;
+    cf* scratch;   // this wave's
+    float* ring;   // this wave's (pv only)
+};
+
+template <bool kRing>
+__device__ __forceinline__ LdsLayout lds_setup(const Tables& tb)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    LdsLayout L;
+    L.hann = reinterpret_cast<float*>(smem);
+    L.t1024 = reinterpret_cast<cf*>(smem + NAE_FFT_N * sizeof(float));
+    unsigned char* wave_base = smem + kLdsTables + (threadIdx.x >> 6) * (kRing ? kLdsPerWavePv : kLdsPerWaveSpec);
+    L.scratch = reinterpret_cast<cf*>(wave_base);
+    L.ring = reinterpret_cast<float*>(wave_base + kScratchCf * sizeof(cf));
+    for (int i = threadIdx.x; i < NAE_FFT_N; i += kThreads) L.hann[i] = tb.hann[i];
+    for (int i = threadIdx.x; i < NAE_FFT_BINS; i += kThreads) L.t1024[i] = tb.t1024[i];
+    __syncthreads();
+    return L;
+}
+
+struct SigViewD { const float* base; long long ss, cs, fs; };
+
+// ------------------------------------------------------------------------------------------------ K8
+// one wave per (stream, frame); channels looped so an interleaved source is fetched by one wave
+__global__ __launch_bounds__(kThreads) void spectrum_kernel(SigViewD src, long long T, int ch, long long n_frames,
+                                                           long long n_items, float* __restrict__ dst,
+                                                           long long dst_ss, Tables tb)
+{
+    LdsLayout L = lds_setup<false>(tb);
+    const int lane = threadIdx.x & 63;
+    const long long item = (long long)blockIdx.x * kWaves + (threadIdx.x >> 6);
+    if (item >= n_items) return;
+    const long long s = item / n_frames, f = item % n_frames;
+    FftTw tw;
+    load_fft_tw(tw, tb.w512, lane);
+    const int kl = kl_of_lane(lane);
+    for (int c = 0; c < ch; c++) {
+        ChanView in{src.base + s * src.ss + c * src.cs, src.fs, T};
+        cf v[8];
+        load_frame_windowed(v, in, f * NAE_HOP, L.hann, lane);
+        fft512_fwd(v, L.scratch, tw, lane);
+        const cf nyq = rfft_split(v, L.scratch, L.t1024, lane);
+        float* o = dst + s * dst_ss + (f * ch + c) * NAE_FFT_BINS;
+#pragma unroll
+        for (int r = 0; r < 8; r++) o[kl + 64 * r] = __builtin_sqrtf(v[r].x * v[r].x + v[r].y * v[r].y);
+        if (lane == 0) o[512] = __builtin_sqrtf(nyq.x * nyq.x + nyq.y * nyq.y);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ K7
+struct PvParams {
+    long long ha_q24;
+    long long in_len;     // valid input sample-frames per stream
+    long long frames;     // F
+    long long mid_len;    // PV-stage output samples wanted
+    int d0;
+    unsigned r_q24_0, r_q24_1;
+    int ch;
+    int tile;             // frames (== output hop blocks) per tile
+    int n_tiles;
+};
+
+__device__ __forceinline__ long long frame_start(const PvParams& p, long long f)
+{
+    return (((f - 1) * p.ha_q24 + (1ll << (NAE_HA_FRAC_BITS - 1))) >> NAE_HA_FRAC_BITS) - NAE_FFT_N / 2;
+}
+
+// analysis of one frame: windowed load, FFT, split.  X[k] for k = kl+64r in v, X[512] returned.
+__device__ __forceinline__ cf analyse(cf (&v)[8], const ChanView& in, long long s, const LdsLayout& L,
+                                      const FftTw& tw, int lane)
+{
+    load_frame_windowed(v, in, s, L.hann, lane);
+    fft512_fwd(v, L.scratch, tw, lane);
+    return rfft_split(v, L.scratch, L.t1024, lane);
+}
+
+__device__ __forceinline__ void phases_of(const cf (&v)[8], cf nyq, uint32_t (&qa)[9])
+{
+#pragma unroll
+    for (int r = 0; r < 8; r++) qa[r] = atan2_q32(v[r].y, v[r].x);
+    qa[8] = atan2_q32(nyq.y, nyq.x);
+}
+
+// phase increment of one hop for this lane's 9 bins (integer, exact)
+__device__ __forceinline__ void phase_inc(const uint32_t (&qa)[9], const uint32_t (&qp)[9], uint32_t (&acc)[9],
+                                          int kl, unsigned d, unsigned R)
+{
+#pragma unroll
+    for (int r = 0; r < 9; r++) {
+        const unsigned k = (r < 8) ? (unsigned)(kl + 64 * r) : 512u;
+        const uint32_t e = ((k * d) & (NAE_FFT_N - 1)) << 22;
+        const int32_t dw = (int32_t)(qa[r] - qp[r] - e);
+        const uint32_t adv = ((k * NAE_HOP) & (NAE_FFT_N - 1)) << 22;
+        const long long scaled = ((long long)dw * (long long)R + (1ll << (NAE_R_FRAC_BITS - 1))) >> NAE_R_FRAC_BITS;
+        acc[r] += adv + (uint32_t)scaled;
+    }
+}
+
+// pass 1: per-tile sum of phase increments.  sums[(sc * n_tiles + tile) * 520 + k]
+__global__ __launch_bounds__(kThreads) void pv_phase_kernel(SigViewD src, PvParams p, long long n_items,
+                                                           uint32_t* __restrict__ sums, Tables tb)
+{
+    LdsLayout L = lds_setup<false>(tb);
+    const int lane = threadIdx.x & 63;
+    const long long item = (long long)blockIdx.x * kWaves + (threadIdx.x >> 6);
+    if (item >= n_items) return;
+    const long long sc = item / p.n_tiles;
+    const int tile = (int)(item % p.n_tiles);
+    const long long s_idx = sc / p.ch;
+    const int c = (int)(sc % p.ch);
+    ChanView in{src.base + s_idx * src.ss + c * src.cs, src.fs, p.in_len};
+    FftTw tw;
+    load_fft_tw(tw, tb.w512, lane);
+    const int kl = kl_of_lane(lane);
+
+    const long long f0 = (long long)tile * p.tile;
+    long long f1 = f0 + p.tile;
+    if (f1 > p.frames) f1 = p.frames;
+
+    uint32_t acc[9], qp[9], qa[9];
+#pragma unroll
+    for (int r = 0; r < 9; r++) acc[r] = 0;
+    cf v[8];
+    long long f = f0;
+    long long s_prev;
+    if (f0 == 0) {
+        s_prev = frame_start(p, 0);
+        const cf nyq = analyse(v, in, s_prev, L, tw, lane);
+        phases_of(v, nyq, qp);
+#pragma unroll
+        for (int r = 0; r < 9; r++) acc[r] = qp[r]; // the "increment" of frame 0 is its analysis phase
+        f = 1;
+    } else {
+        s_prev = frame_start(p, f0 - 1);
+        const cf nyq = analyse(v, in, s_prev, L, tw, lane);
+        phases_of(v, nyq, qp);
+    }
+    for (; f < f1; f++) {
+        const long long s = frame_start(p, f);
+        const cf nyq = analyse(v, in, s, L, tw, lane);
+        phases_of(v, nyq, qa);
+        const unsigned d = (unsigned)(s - s_prev);
+        const unsigned R = (d == (unsigned)p.d0) ? p.r_q24_0 : p.r_q24_1;
+        phase_inc(qa, qp, acc, kl, d, R);
+#pragma unroll
+        for (int r = 0; r < 9; r++) qp[r] = qa[r];
+        s_prev = s;
+    }
+    uint32_t* o = sums + item * kT1024Pad;
+#pragma unroll
+    for (int r = 0; r < 8; r++) o[kl + 64 * r] = acc[r];
+    if (lane == 0) o[512] = acc[8];
+}
+
+// pass 2: exclusive prefix over tiles, in place.  one thread per (stream-channel, bin)
+__global__ void pv_scan_kernel(uint32_t* __restrict__ sums, long long n_sc, int n_tiles)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long sc = t / kT1024Pad;
+    const int k = (int)(t % kT1024Pad);
+    if (sc >= n_sc || k >= NAE_FFT_BINS) return;
+    uint32_t* p = sums + sc * n_tiles * (long long)kT1024Pad + k;
+    uint32_t run = 0;
+    for (int j = 0; j < n_tiles; j++) {
+        const uint32_t v = p[(long long)j * kT1024Pad];
+        p[(long long)j * kT1024Pad] = run;
+        run += v;
+    }
+}
+
+struct OutViewD { float* base; long long ss, cs, fs; };
+
+// pass 3: synthesis of one tile of output hop blocks [tile*T, (tile+1)*T)
+__global__ __launch_bounds__(kThreads) void pv_synth_kernel(SigViewD src, PvParams p, long long n_items,
+                                                           const uint32_t* __restrict__ base_phase, OutViewD out,
+                                                           Tables tb)
+{
+    LdsLayout L = lds_setup<true>(tb);
+    const int lane = threadIdx.x & 63;
+    const long long item = (long long)blockIdx.x * kWaves + (threadIdx.x >> 6);
+    if (item >= n_items) return;
+    const long long sc = item / p.n_tiles;
+    const int tile = (int)(item % p.n_tiles);
+    const long long s_idx = sc / p.ch;
+    const int c = (int)(sc % p.ch);
+    ChanView in{src.base + s_idx * src.ss + c * src.cs, src.fs, p.in_len};
+    float* optr = out.base + s_idx * out.ss + c * out.cs;
+    FftTw tw;
+    load_fft_tw(tw, tb.w512, lane);
+    const int kl = kl_of_lane(lane);
+
+    const long long b0 = (long long)tile * p.tile;          // first output block == first frame of the tile
+    long long f_end = b0 + p.tile + 3;                      // frames b0 .. b0+T+2 feed blocks b0 .. b0+T-1
+    if (f_end > p.frames) f_end = p.frames;
+    const long long b_end = b0 + p.tile;
+
+    uint32_t qs[9], qp[9], qa[9];
+    {
+        const uint32_t* bp = base_phase + item * kT1024Pad;
+#pragma unroll
+        for (int r = 0; r < 8; r++) qs[r] = bp[kl + 64 * r];
+        qs[8] = bp[512];
+    }
+    cf v[8];
+    long long s_prev = 0;
+    if (b0 > 0) {
+        s_prev = frame_start(p, b0 - 1);
+        const cf nyq = analyse(v, in, s_prev, L, tw, lane);
+        phases_of(v, nyq, qp);
+    }
+    for (long long f = b0; f < f_end; f++) {
+        const long long s = frame_start(p, f);
+        const cf nyq = analyse(v, in, s, L, tw, lane);
+        phases_of(v, nyq, qa);
+        if (f == 0) {
+#pragma unroll
+            for (int r = 0; r < 9; r++) qs[r] += qa[r];
+        } else {
+            const unsigned d = (unsigned)(s - s_prev);
+            const unsigned R = (d == (unsigned)p.d0) ? p.r_q24_0 : p.r_q24_1;
+            phase_inc(qa, qp, qs, kl, d, R);
+        }
+#pragma unroll
+        for (int r = 0; r < 9; r++) qp[r] = qa[r];
+        s_prev = s;
+
+        // ---- synthesis spectrum Y = |X| e^{2 pi i qs}, written in natural order (tolerance path from here)
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const float mag = __builtin_amdgcn_sqrtf(__builtin_fmaf(v[r].x, v[r].x, v[r].y * v[r].y));
+            const float ph = (float)(int32_t)qs[r] * (1.0f / 4294967296.0f);
+            cf y{mag * __builtin_amdgcn_cosf(ph), mag * __builtin_amdgcn_sinf(ph)};
+            if (r == 0 && lane == 0) y.y = 0.0f; // c2r ignores Im Y[0]
+            L.scratch[kl + 64 * r] = y;
+        }
+        if (lane == 0) {
+            const float mag = __builtin_amdgcn_sqrtf(__builtin_fmaf(nyq.x, nyq.x, nyq.y * nyq.y));
+            const float ph = (float)(int32_t)qs[8] * (1.0f / 4294967296.0f);
+            L.scratch[512] = cf{mag * __builtin_amdgcn_cosf(ph), 0.0f};
+        }
+        wave_lds_sync();
+        // ---- c2r pre-twiddle into FFT input layout, conjugated (inverse = conj(FFT(conj Z)) / 512)
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int k = lane + 64 * r;
+            const cf Xk = L.scratch[k], Xm = L.scratch[512 - k];
+            const cf T = L.t1024[k];
+            const cf E{0.5f * (Xk.x + Xm.x), 0.5f * (Xk.y - Xm.y)};
+            const cf D{0.5f * (Xk.x - Xm.x), 0.5f * (Xk.y + Xm.y)};
+            const cf Q{__builtin_fmaf(T.x, D.x, T.y * D.y), __builtin_fmaf(T.x, D.y, -(T.y * D.x))};
+            v[r] = cf{E.x - Q.y, -(E.y + Q.x)};
+        }
+        wave_lds_sync();
+        fft512_fwd(v, L.scratch, tw, lane);
+        // v[r] = conj(z[n]) * 512, n = kl + 64 r  ->  time samples 2n, 2n+1
+        // ---- windowed overlap-add into the 4-block ring
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int n2 = 2 * (kl + 64 * r);
+            const float2 w = *reinterpret_cast<const float2*>(L.hann + n2);
+            const float y0 = v[r].x * (1.0f / 512.0f) * w.x;
+            const float y1 = -v[r].y * (1.0f / 512.0f) * w.y;
+            const long long blk = f - 3 + (r >> 1);
+            float2* slot = reinterpret_cast<float2*>(L.ring + (int)(blk & 3) * NAE_HOP + (n2 & (NAE_HOP - 1)));
+            if ((r >> 1) == 3) {
+                *slot = float2{y0, y1};            // newest block: first contribution
+            } else {
+                float2 a = *slot;
+                a.x += y0; a.y += y1;
+                *slot = a;
+            }
+        }
+        wave_lds_sync();
+        // ---- block f-3 is complete
+        const long long be = f - 3;
+        if (be >= b0 && be < b_end) {
+            const long long m0 = be * NAE_HOP + 4 * lane;
+            if (m0 < p.mid_len) {
+                const float4 a = *reinterpret_cast<const float4*>(L.ring + (int)(be & 3) * NAE_HOP + 4 * lane);
+                const float o0 = a.x * NAE_OLA_GAIN, o1 = a.y * NAE_OLA_GAIN, o2 = a.z * NAE_OLA_GAIN,
+                            o3 = a.w * NAE_OLA_GAIN;
+                if (out.fs == 1 && m0 + 4 <= p.mid_len && ((reinterpret_cast<uintptr_t>(optr + m0) & 15) == 0)) {
+                    *reinterpret_cast<float4*>(optr + m0) = float4{o0, o1, o2, o3};
+                } else {
+                    if (m0 + 0 < p.mid_len) optr[(m0 + 0) * out.fs] = o0;
+                    if (m0 + 1 < p.mid_len) optr[(m0 + 1) * out.fs] = o1;
+                    if (m0 + 2 < p.mid_len) optr[(m0 + 2) * out.fs] = o2;
+                    if (m0 + 3 < p.mid_len) optr[(m0 + 3) * out.fs] = o3;
+                }
+            }
+        }
+        wave_lds_sync();
+    }
+}
+
+// rate transposer: out[j] = sum_i tab(phase)[i] * v[idx - 7 + i],  pos = j * step (Q32.32)
+struct RsParams { unsigned long long step_q32; long long src_len; long long out_len; int ch; };
+
+__global__ __launch_bounds__(256) void resample_kernel(SigViewD src, RsParams p, long long n_streams,
+                                                      const float* __restrict__ tab, OutViewD out)
+{
+    __shared__ float stab[(NAE_RS_PHASES + 1) * NAE_RS_TAPS];
+    for (int i = threadIdx.x; i < (NAE_RS_PHASES + 1) * NAE_RS_TAPS; i += blockDim.x) stab[i] = tab[i];
+    __syncthreads();
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long s = blockIdx.y;
+    if (j >= p.out_len) return;
+    const unsigned long long lo = (unsigned long long)j * p.step_q32;
+    const unsigned long long hi = __umul64hi((unsigned long long)j, p.step_q32);
+    const long long idx = (long long)((hi << 32) | (lo >> 32));
+    const unsigned frac = (unsigned)lo;
+    const unsigned ph = frac >> 25;
+    const float alpha = (float)(frac & 0x1FFFFFFu) * (1.0f / 33554432.0f);
+    const float* t0 = stab + ph * NAE_RS_TAPS;
+    const float* t1 = t0 + NAE_RS_TAPS;
+    float coef[NAE_RS_TAPS];
+#pragma unroll
+    for (int i = 0; i < NAE_RS_TAPS; i++) coef[i] = t0[i] + alpha * (t1[i] - t0[i]);
+    for (int c = 0; c < p.ch; c++) {
+        const float* v = src.base + s * src.ss + c * src.cs;
+        float acc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NAE_RS_TAPS; i++) {
+            const long long m = idx - (NAE_RS_TAPS / 2 - 1) + i;
+            const float x = (m >= 0 && m < p.src_len) ? v[m * src.fs] : 0.0f;
+            acc += coef[i] * x;
+        }
+        out.base[s * out.ss + c * out.cs + j * out.fs] = acc;
+    }
+}
+
+} // namespace nae
+
+// ================================================================================================ host side
+using namespace nae;
+
+static inline SigViewD to_view(const nae_sig* s)
+{
+    return SigViewD{static_cast<const float*>(s->base), (long long)s->stream_stride, (long long)s->chan_stride,
+                    (long long)s->frame_stride};
+}
+static inline OutViewD to_out(const nae_sig* s)
+{
+    return OutViewD{static_cast<float*>(s->base), (long long)s->stream_stride, (long long)s->chan_stride,
+                    (long long)s->frame_stride};
+}
+
+int nae_launch_spectrum(nae_ctx* ctx, const nae_sig* src, size_t T, int ch, size_t n_streams, float* dst,
+                        size_t dst_stream_stride)
+{
+    const size_t F = nae_spectrum_frames(T);
+    if (F == 0 || n_streams == 0) return NAE_OK;
+    const long long items = (long long)(F * n_streams);
+    const unsigned grid = (unsigned)((items + kWaves - 1) / kWaves);
+    const size_t lds = kLdsTables + kWaves * kLdsPerWaveSpec;
+    Tables tb{ctx->d_w512, ctx->d_t1024, ctx->d_hann};
+    NAE_KLAUNCH(ctx, "spectrum_kernel", spectrum_kernel, dim3(grid), dim3(kThreads), lds, ctx->stream, to_view(src), (long long)T, ch,
+                       (long long)F, items, dst, (long long)dst_stream_stride, tb);
+    return nae_check(ctx, hipGetLastError(), "spectrum_kernel");
+}
+
+static PvParams make_pv_params(const nae_stretch_plan& pl, size_t in_len, int ch, int tile)
+{
+    PvParams p;
+    p.ha_q24 = pl.ha_q24;
+    p.in_len = (long long)in_len;
+    p.frames = (long long)pl.frames;
+    p.mid_len = (long long)pl.mid_len;
+    p.d0 = pl.d0;
+    p.r_q24_0 = pl.r_q24[0];
+    p.r_q24_1 = pl.r_q24[1];
+    p.ch = ch;
+    p.tile = tile;
+    p.n_tiles = (int)((pl.frames + tile - 1) / tile);
+    return p;
+}
+
+size_t nae_pv_phase_workspace_bytes(const nae_stretch_plan* pl, int ch, size_t n_streams, int tile)
+{
+    const size_t n_tiles = (pl->frames + tile - 1) / tile;
+    return n_streams * ch * n_tiles * kT1024Pad * sizeof(uint32_t);
+}
+
+// pass 1 + 2: leaves the exclusive tile-prefix phases in `phase_ws`
+int nae_launch_pv_phase(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig* src, size_t in_len, int ch,
+                        size_t n_streams, int tile, uint32_t* phase_ws)
+{
+    PvParams p = make_pv_params(*pl, in_len, ch, tile);
+    const long long items = (long long)n_streams * ch * p.n_tiles;
+    if (items == 0) return NAE_OK;
+    Tables tb{ctx->d_w512, ctx->d_t1024, ctx->d_hann};
+    {
+        const unsigned grid = (unsigned)((items + kWaves - 1) / kWaves);
+        const size_t lds = kLdsTables + kWaves * kLdsPerWaveSpec;
+        NAE_KLAUNCH(ctx, "pv_phase_kernel", pv_phase_kernel, dim3(grid), dim3(kThreads), lds, ctx->stream, to_view(src), p, items,
+                           phase_ws, tb);
+        int rc = nae_check(ctx, hipGetLastError(), "pv_phase_kernel");
+        if (rc) return rc;
+    }
+    {
+        const long long n_sc = (long long)n_streams * ch;
+        const long long threads = n_sc * kT1024Pad;
+        const unsigned grid = (unsigned)((threads + 255) / 256);
+        NAE_KLAUNCH(ctx, "pv_scan_kernel", pv_scan_kernel, dim3(grid), dim3(256), 0, ctx->stream, phase_ws, n_sc, p.n_tiles);
+        return nae_check(ctx, hipGetLastError(), "pv_scan_kernel");
+    }
+}
+
+int nae_launch_pv_synth(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig* src, size_t in_len, int ch,
+                        size_t n_streams, int tile, const uint32_t* phase_ws, const nae_sig* out)
+{
+    PvParams p = make_pv_params(*pl, in_len, ch, tile);
+    const long long items = (long long)n_streams * ch * p.n_tiles;
+    if (items == 0) return NAE_OK;
+    Tables tb{ctx->d_w512, ctx->d_t1024, ctx->d_hann};
+    const unsigned grid = (unsigned)((items + kWaves - 1) / kWaves);
+    const size_t lds = kLdsTables + kWaves * kLdsPerWavePv;
+    NAE_KLAUNCH(ctx, "pv_synth_kernel", pv_synth_kernel, dim3(grid), dim3(kThreads), lds, ctx->stream, to_view(src), p, items,
+                       phase_ws, to_out(out), tb);
+    return nae_check(ctx, hipGetLastError(), "pv_synth_kernel");
+}
+
+int nae_launch_resample(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig* src, size_t src_len, int ch,
+                        size_t n_streams, const float* d_tab, const nae_sig* out)
+{
+    if (pl->out_len == 0 || n_streams == 0) return NAE_OK;
+    RsParams p{pl->step_q32, (long long)src_len, (long long)pl->out_len, ch};
+    const unsigned gx = (unsigned)((pl->out_len + 255) / 256);
+    // blockIdx.y is limited to 65535
+    for (size_t s0 = 0; s0 < n_streams; s0 += 65535) {
+        const size_t ns = (n_streams - s0 < 65535) ? n_streams - s0 : 65535;
+        SigViewD sv = to_view(src);
+        OutViewD ov = to_out(out);
+        sv.base += (long long)s0 * sv.ss;
+        ov.base += (long long)s0 * ov.ss;
+        NAE_KLAUNCH(ctx, "resample_kernel", resample_kernel, dim3(gx, (unsigned)ns), dim3(256), 0, ctx->stream, sv, p, (long long)ns,
+                           d_tab, ov);
+        int rc = nae_check(ctx, hipGetLastError(), "resample_kernel");
+        if (rc) return rc;
+    }
+    return NAE_OK;
+}
+
+size_t nae_lds_bytes_pv(void) { return kLdsTables + kWaves * kLdsPerWavePv; }

@@ -1,0 +1,465 @@
+// nae_api.hip — context, plumbing, and the host-side orchestration of K7/K8 behind the C ABI (include/nae_gpu.h).
+// No CPU compute path exists in this library: every transform is a HIP kernel launch; if HIP is unusable the
+// entry points fail with NAE_ERR_HIP.
+#include "nae_internal.h"
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <new>
+
+namespace nae { struct cf { float x, y; }; }
+
+int nae_fail(nae_ctx* ctx, int code, const char* what)
+{
+    if (ctx) snprintf(ctx->err, sizeof ctx->err, "%s", what);
+    return code;
+}
+
+int nae_check(nae_ctx* ctx, hipError_t e, const char* what)
+{
+    if (e == hipSuccess) return NAE_OK;
+    if (ctx) snprintf(ctx->err, sizeof ctx->err, "%s: %s", what, hipGetErrorString(e));
+    return NAE_ERR_HIP;
+}
+
+NaeProfScope::NaeProfScope(nae_ctx* c, const char* name) : ctx(c), idx(-1)
+{
+    if (!c || !c->prof_on) return;
+    int slot = -1;
+    for (size_t i = 0; i < c->prof_slots.size(); i++)
+        if (c->prof_slots[i].name == name || !strcmp(c->prof_slots[i].name, name)) { slot = (int)i; break; }
+    if (slot < 0) { c->prof_slots.push_back({name, 0.0, 0}); slot = (int)c->prof_slots.size() - 1; }
+    nae_ctx::ProfPair pp{slot, nullptr, nullptr};
+    if (hipEventCreate(&pp.a) != hipSuccess || hipEventCreate(&pp.b) != hipSuccess) return;
+    (void)hipEventRecord(pp.a, c->stream);
+    c->prof_pairs.push_back(pp);
+    idx = (int)c->prof_pairs.size() - 1;
+}
+NaeProfScope::~NaeProfScope()
+{
+    if (idx >= 0) (void)hipEventRecord(ctx->prof_pairs[idx].b, ctx->stream);
+}
+
+static void prof_collect(nae_ctx* ctx)
+{
+    if (ctx->prof_pairs.empty()) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& pp : ctx->prof_pairs) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, pp.a, pp.b) == hipSuccess) {
+            ctx->prof_slots[pp.slot].total_ms += ms;
+            ctx->prof_slots[pp.slot].launches += 1;
+        }
+        (void)hipEventDestroy(pp.a);
+        (void)hipEventDestroy(pp.b);
+    }
+    ctx->prof_pairs.clear();
+}
+
+int nae_ws_reserve(nae_ctx* ctx, void** p, size_t* have, size_t want)
+{
+    if (*have >= want && *p) return NAE_OK;
+    if (*p) {
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) return nae_check(ctx, e, "hipStreamSynchronize");
+        (void)hipFree(*p);
+        *p = nullptr;
+        *have = 0;
+    }
+    size_t bytes = want + want / 8 + 4096;
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) { *p = nullptr; return nae_check(ctx, e, "hipMalloc(workspace)") == NAE_ERR_HIP ? NAE_ERR_NOMEM : NAE_ERR_NOMEM; }
+    *have = bytes;
+    return NAE_OK;
+}
+
+static void build_tables(std::vector<nae::cf>& w512, std::vector<nae::cf>& t1024, std::vector<float>& hann)
+{
+    const double two_pi = 6.283185307179586476925286766559;
+    w512.resize(512);
+    t1024.resize(513);
+    hann.resize(1024);
+    for (int k = 0; k < 512; k++) w512[k] = nae::cf{(float)cos(two_pi * k / 512.0), (float)(-sin(two_pi * k / 512.0))};
+    for (int k = 0; k <= 512; k++) t1024[k] = nae::cf{(float)cos(two_pi * k / 1024.0), (float)(-sin(two_pi * k / 1024.0))};
+    for (int n = 0; n < 1024; n++) hann[n] = (float)(0.5 - 0.5 * cos(two_pi * n / 1024.0));
+}
+
+static double bessel_i0(double x)
+{
+    double sum = 1.0, term = 1.0;
+    const double q = x * x / 4.0;
+    for (int k = 1; k < 64; k++) {
+        term *= q / ((double)k * (double)k);
+        sum += term;
+        if (term < 1e-18 * sum) break;
+    }
+    return sum;
+}
+
+static void build_rs_table(double rate_eff, std::vector<float>& tab)
+{
+    const double pi = 3.14159265358979323846;
+    const double c = NAE_RS_CUTOFF * (rate_eff > 1.0 ? 1.0 / rate_eff : 1.0);
+    const double half = NAE_RS_TAPS / 2.0;
+    const double i0b = bessel_i0(NAE_RS_KAISER_BETA);
+    tab.resize((NAE_RS_PHASES + 1) * NAE_RS_TAPS);
+    for (int p = 0; p <= NAE_RS_PHASES; p++) {
+        double row[NAE_RS_TAPS], sum = 0.0;
+        for (int i = 0; i < NAE_RS_TAPS; i++) {
+            const double x = (double)(i - (NAE_RS_TAPS / 2 - 1)) - (double)p / NAE_RS_PHASES;
+            const double a = x / half;
+            double w = 0.0;
+            if (a > -1.0 && a < 1.0) w = bessel_i0(NAE_RS_KAISER_BETA * sqrt(1.0 - a * a)) / i0b;
+            else if (a == 1.0 || a == -1.0) w = 1.0 / i0b;
+            const double arg = pi * c * x;
+            const double sinc = (fabs(arg) < 1e-12) ? 1.0 : sin(arg) / arg;
+            row[i] = c * sinc * w;
+            sum += row[i];
+        }
+        for (int i = 0; i < NAE_RS_TAPS; i++) tab[p * NAE_RS_TAPS + i] = (float)(row[i] / sum);
+    }
+}
+
+static int ensure_rs_table(nae_ctx* ctx, double rate_eff)
+{
+    if (ctx->d_rs_tab && ctx->rs_tab_rate == rate_eff) return NAE_OK;
+    if (!ctx->d_rs_tab) {
+        hipError_t e = hipMalloc((void**)&ctx->d_rs_tab, (NAE_RS_PHASES + 1) * NAE_RS_TAPS * sizeof(float));
+        if (e != hipSuccess) return nae_check(ctx, e, "hipMalloc(rs table)");
+    } else {
+        hipError_t e = hipStreamSynchronize(ctx->stream); // the previous table may still be in use
+        if (e != hipSuccess) return nae_check(ctx, e, "hipStreamSynchronize");
+    }
+    build_rs_table(rate_eff, ctx->h_rs_tab);
+    hipError_t e = hipMemcpy(ctx->d_rs_tab, ctx->h_rs_tab.data(), ctx->h_rs_tab.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return nae_check(ctx, e, "hipMemcpy(rs table)");
+    ctx->rs_tab_rate = rate_eff;
+    return NAE_OK;
+}
+
+extern "C" {
+
+int nae_abi_version(void) { return NAE_ABI_VERSION; }
+
+int nae_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int nae_ctx_create(int device, nae_ctx** out)
+{
+    if (!out) return NAE_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return NAE_ERR_HIP;
+    if (device < 0 || device >= n) return NAE_ERR_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return NAE_ERR_HIP;
+    nae_ctx* ctx = new (std::nothrow) nae_ctx();
+    if (!ctx) return NAE_ERR_NOMEM;
+    ctx->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) snprintf(ctx->name, sizeof ctx->name, "%s (%s)", prop.name, prop.gcnArchName);
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return NAE_ERR_HIP; }
+    ctx->own_stream = true;
+    std::vector<nae::cf> w512, t1024;
+    std::vector<float> hann;
+    build_tables(w512, t1024, hann);
+    bool ok = hipMalloc((void**)&ctx->d_w512, 512 * sizeof(nae::cf)) == hipSuccess &&
+              hipMalloc((void**)&ctx->d_t1024, 520 * sizeof(nae::cf)) == hipSuccess &&
+              hipMalloc((void**)&ctx->d_hann, 1024 * sizeof(float)) == hipSuccess;
+    ok = ok && hipMemcpy(ctx->d_w512, w512.data(), 512 * sizeof(nae::cf), hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(ctx->d_t1024, t1024.data(), 513 * sizeof(nae::cf), hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(ctx->d_hann, hann.data(), 1024 * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) { nae_ctx_destroy(ctx); return NAE_ERR_HIP; }
+    *out = ctx;
+    return NAE_OK;
+}
+
+int nae_ctx_destroy(nae_ctx* ctx)
+{
+    if (!ctx) return NAE_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    prof_collect(ctx);
+    if (ctx->d_w512) (void)hipFree(ctx->d_w512);
+    if (ctx->d_t1024) (void)hipFree(ctx->d_t1024);
+    if (ctx->d_hann) (void)hipFree(ctx->d_hann);
+    if (ctx->d_rs_tab) (void)hipFree(ctx->d_rs_tab);
+    if (ctx->ws_phase) (void)hipFree(ctx->ws_phase);
+    if (ctx->ws_mid) (void)hipFree(ctx->ws_mid);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return NAE_OK;
+}
+
+int nae_ctx_set_stream(nae_ctx* ctx, void* hip_stream)
+{
+    if (!ctx) return NAE_ERR_INVALID;
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    ctx->stream = static_cast<hipStream_t>(hip_stream);
+    ctx->own_stream = false;
+    return NAE_OK;
+}
+
+void* nae_ctx_stream(nae_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int nae_sync(nae_ctx* ctx)
+{
+    if (!ctx) return NAE_ERR_INVALID;
+    return nae_check(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+}
+
+int nae_poll(nae_ctx* ctx)
+{
+    if (!ctx) return NAE_ERR_INVALID;
+    hipError_t e = hipStreamQuery(ctx->stream);
+    if (e == hipSuccess) return 1;
+    if (e == hipErrorNotReady) return 0;
+    return nae_check(ctx, e, "hipStreamQuery");
+}
+
+const char* nae_last_error(nae_ctx* ctx) { return ctx ? ctx->err : "null context"; }
+const char* nae_device_name(nae_ctx* ctx) { return ctx ? ctx->name : ""; }
+
+int nae_malloc(nae_ctx* ctx, size_t bytes, void** dptr)
+{
+    if (!ctx || !dptr) return NAE_ERR_INVALID;
+    *dptr = nullptr;
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(dptr, bytes);
+    if (e != hipSuccess) { nae_check(ctx, e, "hipMalloc"); return NAE_ERR_NOMEM; }
+    return NAE_OK;
+}
+int nae_free(nae_ctx* ctx, void* dptr)
+{
+    if (!dptr) return NAE_OK;
+    return nae_check(ctx, hipFree(dptr), "hipFree");
+}
+int nae_memcpy_h2d(nae_ctx* ctx, void* dst, const void* src, size_t bytes)
+{
+    if (!ctx || (bytes && (!dst || !src))) return NAE_ERR_INVALID;
+    return nae_check(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync(h2d)");
+}
+int nae_memcpy_d2h(nae_ctx* ctx, void* dst, const void* src, size_t bytes)
+{
+    if (!ctx || (bytes && (!dst || !src))) return NAE_ERR_INVALID;
+    return nae_check(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync(d2h)");
+}
+int nae_memcpy_d2d(nae_ctx* ctx, void* dst, const void* src, size_t bytes)
+{
+    if (!ctx || (bytes && (!dst || !src))) return NAE_ERR_INVALID;
+    return nae_check(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream), "hipMemcpyAsync(d2d)");
+}
+int nae_memset(nae_ctx* ctx, void* dst, int value, size_t bytes)
+{
+    if (!ctx || (bytes && !dst)) return NAE_ERR_INVALID;
+    return nae_check(ctx, hipMemsetAsync(dst, value, bytes, ctx->stream), "hipMemsetAsync");
+}
+
+int nae_event_create(nae_ctx* ctx, nae_event** ev)
+{
+    if (!ctx || !ev) return NAE_ERR_INVALID;
+    nae_event* e = new (std::nothrow) nae_event();
+    if (!e) return NAE_ERR_NOMEM;
+    if (hipEventCreate(&e->ev) != hipSuccess) { delete e; return NAE_ERR_HIP; }
+    *ev = e;
+    return NAE_OK;
+}
+int nae_event_record(nae_ctx* ctx, nae_event* ev)
+{
+    if (!ctx || !ev) return NAE_ERR_INVALID;
+    return nae_check(ctx, hipEventRecord(ev->ev, ctx->stream), "hipEventRecord");
+}
+int nae_event_elapsed_ms(nae_event* start, nae_event* stop, float* ms)
+{
+    if (!start || !stop || !ms) return NAE_ERR_INVALID;
+    if (hipEventSynchronize(stop->ev) != hipSuccess) return NAE_ERR_HIP;
+    return hipEventElapsedTime(ms, start->ev, stop->ev) == hipSuccess ? NAE_OK : NAE_ERR_HIP;
+}
+int nae_event_destroy(nae_event* ev)
+{
+    if (!ev) return NAE_OK;
+    (void)hipEventDestroy(ev->ev);
+    delete ev;
+    return NAE_OK;
+}
+
+int nae_prof_enable(nae_ctx* ctx, int on)
+{
+    if (!ctx) return NAE_ERR_INVALID;
+    prof_collect(ctx);
+    ctx->prof_on = on != 0;
+    return NAE_OK;
+}
+int nae_prof_reset(nae_ctx* ctx)
+{
+    if (!ctx) return NAE_ERR_INVALID;
+    prof_collect(ctx);
+    ctx->prof_slots.clear();
+    return NAE_OK;
+}
+int nae_prof_get(nae_ctx* ctx, int index, char* name, size_t name_cap, double* total_ms, uint64_t* launches)
+{
+    if (!ctx) return NAE_ERR_INVALID;
+    prof_collect(ctx);
+    if (index < 0 || index >= (int)ctx->prof_slots.size()) return (int)ctx->prof_slots.size();
+    if (name && name_cap) snprintf(name, name_cap, "%s", ctx->prof_slots[index].name);
+    if (total_ms) *total_ms = ctx->prof_slots[index].total_ms;
+    if (launches) *launches = ctx->prof_slots[index].launches;
+    return (int)ctx->prof_slots.size();
+}
+
+// ------------------------------------------------------------------------------------------------ K7 plan
+// Parameter resolution, DESIGN.md §3.2.  SoundTouch mapping (audio-velocity.cpp:384-385): setRate(rate) and
+// setPitch(pitch) give a time-stretch of 1/pitch followed by a resampling of rate*pitch.
+int nae_stretch_plan_make(double rate, double pitch, size_t in_len, nae_stretch_plan* pl)
+{
+    if (!pl) return NAE_ERR_INVALID;
+    memset(pl, 0, sizeof *pl);
+    if (!(rate > 0.0) || !(pitch > 0.0)) return NAE_ERR_INVALID;
+    double tempo = 1.0 / pitch, rho = rate * pitch;
+    if (fabs(tempo - 1.0) < 1e-6) tempo = 1.0;
+    if (fabs(rho - 1.0) < 1e-6) rho = 1.0;
+    pl->pv_on = tempo != 1.0;
+    pl->rs_on = rho != 1.0;
+    if (pl->pv_on && (tempo < NAE_TEMPO_MIN || tempo > NAE_TEMPO_MAX)) return NAE_ERR_UNSUPPORTED;
+    if (pl->rs_on && (rho < NAE_RATE_MIN || rho > NAE_RATE_MAX)) return NAE_ERR_UNSUPPORTED;
+    pl->tempo_eff = tempo;
+    pl->rate_eff = rho;
+    pl->ha_q24 = (int64_t)llround((double)NAE_HOP * tempo * (double)(1 << NAE_HA_FRAC_BITS));
+    pl->d0 = (int32_t)(pl->ha_q24 >> NAE_HA_FRAC_BITS);
+    for (int i = 0; i < 2; i++) {
+        const uint64_t d = (uint64_t)(pl->d0 + i);
+        pl->r_q24[i] = (uint32_t)((((uint64_t)NAE_HOP << NAE_R_FRAC_BITS) + d / 2) / d);
+    }
+    pl->step_q32 = (uint64_t)llround(rho * 4294967296.0);
+    pl->out_len = (size_t)floor((double)in_len / (tempo * rho) + 0.5);
+    if (pl->rs_on) {
+        if (pl->out_len == 0) pl->mid_len = 0;
+        else {
+            const unsigned __int128 pos = (unsigned __int128)(pl->out_len - 1) * pl->step_q32;
+            pl->mid_len = (size_t)(pos >> 32) + NAE_RS_TAPS / 2 + 1;
+        }
+    } else
+        pl->mid_len = pl->out_len;
+    pl->frames = pl->pv_on ? (pl->mid_len + NAE_FFT_N / 2 + NAE_HOP - 1) / NAE_HOP + 1 : 0;
+    return NAE_OK;
+}
+
+static int check_sig(nae_ctx* ctx, const nae_sig* s, const char* what)
+{
+    if (!s || !s->base) return nae_fail(ctx, NAE_ERR_INVALID, what);
+    return NAE_OK;
+}
+
+int nae_stretch_block_f32(nae_ctx* ctx, double rate, double pitch, const nae_sig* src, size_t in_len, int ch,
+                          size_t n_streams, const nae_sig* dst)
+{
+    if (!ctx) return NAE_ERR_INVALID;
+    int rc;
+    if ((rc = check_sig(ctx, src, "null source view")) || (rc = check_sig(ctx, dst, "null destination view"))) return rc;
+    if (ch < 1 || ch > 2) return nae_fail(ctx, NAE_ERR_INVALID, "channel count must be 1 or 2");
+    nae_stretch_plan pl;
+    rc = nae_stretch_plan_make(rate, pitch, in_len, &pl);
+    if (rc) return nae_fail(ctx, rc, "rate/pitch outside the supported range");
+    if (n_streams == 0 || pl.out_len == 0) return NAE_OK;
+    if (!pl.pv_on && !pl.rs_on) return nae_launch_copy_sig(ctx, src, dst, in_len, ch, n_streams, false, 1.0f);
+
+    const nae_sig* rs_src = src;
+    size_t rs_src_len = in_len;
+    nae_sig mid{};
+    if (pl.pv_on) {
+        const int tile = ctx->pv_tile;
+        rc = nae_ws_reserve(ctx, &ctx->ws_phase, &ctx->ws_phase_bytes, nae_pv_phase_workspace_bytes(&pl, ch, n_streams, tile));
+        if (rc) return rc;
+        const nae_sig* pv_out = dst;
+        if (pl.rs_on) {
+            const size_t mid_stride = (pl.mid_len + 3) & ~(size_t)3;
+            rc = nae_ws_reserve(ctx, &ctx->ws_mid, &ctx->ws_mid_bytes, n_streams * ch * mid_stride * sizeof(float));
+            if (rc) return rc;
+            mid = nae_sig{ctx->ws_mid, (size_t)ch * mid_stride, mid_stride, 1};
+            pv_out = &mid;
+            rs_src = &mid;
+            rs_src_len = pl.mid_len;
+        }
+        rc = nae_launch_pv_phase(ctx, &pl, src, in_len, ch, n_streams, tile, static_cast<uint32_t*>(ctx->ws_phase));
+        if (rc) return rc;
+        rc = nae_launch_pv_synth(ctx, &pl, src, in_len, ch, n_streams, tile, static_cast<const uint32_t*>(ctx->ws_phase), pv_out);
+        if (rc) return rc;
+    }
+    if (pl.rs_on) {
+        rc = ensure_rs_table(ctx, pl.rate_eff);
+        if (rc) return rc;
+        rc = nae_launch_resample(ctx, &pl, rs_src, rs_src_len, ch, n_streams, ctx->d_rs_tab, dst);
+        if (rc) return rc;
+    }
+    return NAE_OK;
+}
+
+int nae_debug_pv_tile_phase(nae_ctx* ctx, double rate, double pitch, const nae_sig* src, size_t in_len, int ch,
+                            size_t n_streams, int32_t* dst_host, size_t dst_capacity, size_t* n_tiles_out,
+                            size_t* tile_frames)
+{
+    if (!ctx || !dst_host || !n_tiles_out || !tile_frames) return NAE_ERR_INVALID;
+    int rc = check_sig(ctx, src, "null source view");
+    if (rc) return rc;
+    nae_stretch_plan pl;
+    rc = nae_stretch_plan_make(rate, pitch, in_len, &pl);
+    if (rc) return nae_fail(ctx, rc, "rate/pitch outside the supported range");
+    if (!pl.pv_on) return nae_fail(ctx, NAE_ERR_STATE, "phase vocoder stage is bypassed for these parameters");
+    const int tile = ctx->pv_tile;
+    const size_t n_tiles = (pl.frames + tile - 1) / tile;
+    *n_tiles_out = n_tiles;
+    *tile_frames = (size_t)tile;
+    const size_t need = n_streams * ch * n_tiles * NAE_FFT_BINS;
+    if (dst_capacity < need) return nae_fail(ctx, NAE_ERR_INVALID, "destination too small");
+    const size_t ws_bytes = nae_pv_phase_workspace_bytes(&pl, ch, n_streams, tile);
+    rc = nae_ws_reserve(ctx, &ctx->ws_phase, &ctx->ws_phase_bytes, ws_bytes);
+    if (rc) return rc;
+    rc = nae_launch_pv_phase(ctx, &pl, src, in_len, ch, n_streams, tile, static_cast<uint32_t*>(ctx->ws_phase));
+    if (rc) return rc;
+    std::vector<int32_t> tmp(ws_bytes / sizeof(int32_t));
+    hipError_t e = hipMemcpyAsync(tmp.data(), ctx->ws_phase, ws_bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return nae_check(ctx, e, "copy phase workspace");
+    for (size_t rec = 0; rec < n_streams * ch * n_tiles; rec++)
+        memcpy(dst_host + rec * NAE_FFT_BINS, tmp.data() + rec * kPhasePad, NAE_FFT_BINS * sizeof(int32_t));
+    return NAE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ K8
+size_t nae_spectrum_frames(size_t T) { return T < NAE_FFT_N ? 0 : (T - NAE_FFT_N) / NAE_HOP + 1; }
+
+int nae_spectrum_block_f32(nae_ctx* ctx, const nae_sig* src, size_t T, int ch, size_t n_streams, float* dst,
+                           size_t dst_stream_stride)
+{
+    if (!ctx || !dst) return NAE_ERR_INVALID;
+    int rc = check_sig(ctx, src, "null source view");
+    if (rc) return rc;
+    if (ch < 1 || ch > 2) return nae_fail(ctx, NAE_ERR_INVALID, "channel count must be 1 or 2");
+    return nae_launch_spectrum(ctx, src, T, ch, n_streams, dst, dst_stream_stride);
+}
+
+// ------------------------------------------------------------------------------------------------ graph
+int nae_graph4_run(nae_ctx* ctx, const nae_graph4* g)
+{
+    if (!ctx || !g) return NAE_ERR_INVALID;
+    // node 1+2: the two inputs feed the 2-input mixer (audio-amix.cpp:86-324 with input_num = 2)
+    const nae_sig ins[2] = {g->in_a, g->in_b};
+    const float vol[2] = {g->vol_a, g->vol_b};
+    int rc = nae_amix_sig_f32(ctx, ins, vol, 2, &g->mix_out, g->S, g->n_streams);
+    if (rc) return rc;
+    // node 3: pitch (audio-velocity.cpp:462-477)
+    rc = nae_stretch_block_f32(ctx, g->rate, g->pitch, &g->mix_out, g->S, 2, g->n_streams, &g->pitch_out);
+    if (rc) return rc;
+    nae_stretch_plan pl;
+    rc = nae_stretch_plan_make(g->rate, g->pitch, g->S, &pl);
+    if (rc) return rc;
+    // node 4: spectrum
+    return nae_spectrum_block_f32(ctx, &g->pitch_out, pl.out_len, 2, g->n_streams, g->spec_out, g->spec_stream_stride);
+}
+
+} // extern "C"

@@ -1,0 +1,69 @@
+// nae_internal.h — shared between the translation units of libnae_gpu.so (not installed)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <vector>
+#include "../../include/nae_gpu.h"
+#include "../../include/nae_dsp_spec.h"
+
+namespace nae { struct cf; }
+
+struct nae_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    char err[512] = {0};
+    char name[256] = {0};
+    // read-only tables (built on the host in double, rounded once to f32)
+    nae::cf* d_w512 = nullptr;   // exp(-2 pi i k/512),  k = 0..511
+    nae::cf* d_t1024 = nullptr;  // exp(-2 pi i k/1024), k = 0..512
+    float* d_hann = nullptr;     // periodic Hann, 1024
+    // grow-only workspaces
+    void* ws_phase = nullptr; size_t ws_phase_bytes = 0;
+    void* ws_mid = nullptr;   size_t ws_mid_bytes = 0;
+    float* d_rs_tab = nullptr; double rs_tab_rate = 0.0;
+    std::vector<float> h_rs_tab;
+    int pv_tile = 64;            // frames per phase-vocoder tile
+    // optional per-kernel timing (hipEvent pairs on the ctx stream), used by bench.py for the roofline line
+    bool prof_on = false;
+    struct ProfSlot { const char* name; double total_ms; uint64_t launches; };
+    struct ProfPair { int slot; hipEvent_t a, b; };
+    std::vector<ProfSlot> prof_slots;
+    std::vector<ProfPair> prof_pairs;
+};
+
+// RAII: brackets one kernel launch with two events when profiling is on
+struct NaeProfScope {
+    nae_ctx* ctx; int idx;
+    NaeProfScope(nae_ctx* c, const char* name);
+    ~NaeProfScope();
+};
+
+#define NAE_KLAUNCH(ctx, name_str, ...)          \
+    do {                                          \
+        NaeProfScope nae_ps_(ctx, name_str);      \
+        hipLaunchKernelGGL(__VA_ARGS__);          \
+    } while (0)
+
+struct nae_event { hipEvent_t ev; };
+
+int nae_check(nae_ctx* ctx, hipError_t e, const char* what);
+int nae_fail(nae_ctx* ctx, int code, const char* what);
+int nae_ws_reserve(nae_ctx* ctx, void** p, size_t* have, size_t want);
+
+// kernels_stft.hip
+int nae_launch_spectrum(nae_ctx* ctx, const nae_sig* src, size_t T, int ch, size_t n_streams, float* dst,
+                        size_t dst_stream_stride);
+size_t nae_pv_phase_workspace_bytes(const nae_stretch_plan* pl, int ch, size_t n_streams, int tile);
+int nae_launch_pv_phase(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig* src, size_t in_len, int ch,
+                        size_t n_streams, int tile, uint32_t* phase_ws);
+int nae_launch_pv_synth(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig* src, size_t in_len, int ch,
+                        size_t n_streams, int tile, const uint32_t* phase_ws, const nae_sig* out);
+int nae_launch_resample(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig* src, size_t src_len, int ch,
+                        size_t n_streams, const float* d_tab, const nae_sig* out);
+constexpr int kPhasePad = 520; // int32 per (stream-channel, tile) record in the phase workspace
+
+// kernels_nodes.hip
+int nae_launch_copy_sig(nae_ctx* ctx, const nae_sig* src, const nae_sig* dst, size_t S, int ch, size_t n_streams,
+                        bool scale, float volume);

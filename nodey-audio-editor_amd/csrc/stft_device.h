@@ -1,0 +1,209 @@
+// stft_device.h — wave-level STFT building blocks for gfx950 (CDNA4, wave64).
+//
+// One wavefront owns one 1024-sample frame: the 512 packed complex points live 8 per lane (16 VGPRs);
+// the 512-point FFT is three register-resident radix-8 passes with two transposes through a wave-private
+// LDS scratch (no workgroup barrier anywhere: DS operations of one wave execute in order).
+//
+// The operation order of everything up to the Q0.32 phase is the canonical one of DESIGN.md §3 so that the
+// integer phases equal the CPU oracle's bit for bit.  This translation unit is compiled with
+// -ffp-contract=off; fused multiply-adds appear only where __builtin_fmaf is written.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/nae_dsp_spec.h"
+
+namespace nae {
+
+struct cf { float x, y; };
+struct __attribute__((packed, aligned(4))) f2u { float x, y; }; // 8-byte access at 4-byte alignment
+
+constexpr int kScratchCf = 576;                 // per-wave LDS scratch, complex elements (8 rows x 72, or 513 natural)
+constexpr int kScratchRow = 72;                 // padded row stride of the transpose images
+constexpr int kRingFloats = 4 * NAE_HOP;        // per-wave overlap-add ring: 4 hop blocks
+
+__device__ __forceinline__ void wave_lds_sync()
+{
+    // order this wave's LDS writes before its following LDS reads (other lanes' data); no instruction
+    // beyond the waitcnt the compiler already tracks — DS ops of one wave are executed in issue order.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ cf cmul_tw(cf v, cf w)
+{
+    cf r;
+    r.x = __builtin_fmaf(-v.y, w.y, v.x * w.x);
+    r.y = __builtin_fmaf(v.y, w.x, v.x * w.y);
+    return r;
+}
+__device__ __forceinline__ cf cadd(cf a, cf b) { return cf{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ cf csub(cf a, cf b) { return cf{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ cf mul_mi(cf a) { return cf{a.y, -a.x}; }
+
+// canonical forward 8-point DFT, in place, natural-order output
+__device__ __forceinline__ void dft8_fwd(cf (&a)[8])
+{
+    const float c = NAE_SQRT1_2;
+    const cf s0 = cadd(a[0], a[4]), d0 = csub(a[0], a[4]);
+    const cf s1 = cadd(a[1], a[5]), e1 = csub(a[1], a[5]);
+    const cf s2 = cadd(a[2], a[6]), e2 = csub(a[2], a[6]);
+    const cf s3 = cadd(a[3], a[7]), e3 = csub(a[3], a[7]);
+    const cf d1 = cf{(e1.x + e1.y) * c, (e1.y - e1.x) * c};
+    const cf d2 = mul_mi(e2);
+    const cf d3 = cf{(e3.y - e3.x) * c, -((e3.x + e3.y) * c)};
+    const cf t0 = cadd(s0, s2), t1 = csub(s0, s2), t2 = cadd(s1, s3), t3 = mul_mi(csub(s1, s3));
+    const cf u0 = cadd(d0, d2), u1 = csub(d0, d2), u2 = cadd(d1, d3), u3 = mul_mi(csub(d1, d3));
+    a[0] = cadd(t0, t2); a[4] = csub(t0, t2); a[2] = cadd(t1, t3); a[6] = csub(t1, t3);
+    a[1] = cadd(u0, u2); a[5] = csub(u0, u2); a[3] = cadd(u1, u3); a[7] = csub(u1, u3);
+}
+
+// per-lane twiddles of the two twiddled passes, loop-invariant across frames
+struct FftTw {
+    cf a[7]; // W512^(lane*q),        q = 1..7
+    cf b[7]; // W512^(8*(lane&7)*p),  p = 1..7
+};
+
+__device__ __forceinline__ void load_fft_tw(FftTw& tw, const cf* __restrict__ w512, int lane)
+{
+#pragma unroll
+    for (int q = 1; q < 8; q++) tw.a[q - 1] = w512[lane * q];
+#pragma unroll
+    for (int p = 1; p < 8; p++) tw.b[p - 1] = w512[8 * (lane & 7) * p];
+}
+
+// bin / packed-sample index held by (lane, register r) after the forward FFT:  k = kl(lane) + 64 r
+__device__ __forceinline__ int kl_of_lane(int lane) { return (lane >> 3) + 8 * (lane & 7); }
+
+// canonical forward 512-point FFT.  in: v[j] = z[lane + 64 j];  out: v[r] = Z[kl(lane) + 64 r].
+__device__ __forceinline__ void fft512_fwd(cf (&v)[8], cf* __restrict__ scratch, const FftTw& tw, int lane)
+{
+    // pass A
+    dft8_fwd(v);
+#pragma unroll
+    for (int q = 1; q < 8; q++) v[q] = cmul_tw(v[q], tw.a[q - 1]);
+    // transpose 1: u1[q][l] -> lane (m = lane&7, q' = lane>>3) register j = u1[q'][m + 8 j]
+#pragma unroll
+    for (int q = 0; q < 8; q++) scratch[q * kScratchRow + lane] = v[q];
+    wave_lds_sync();
+    {
+        const int base = (lane >> 3) * kScratchRow + (lane & 7);
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = scratch[base + 8 * j];
+    }
+    wave_lds_sync();
+    // pass B
+    dft8_fwd(v);
+#pragma unroll
+    for (int p = 1; p < 8; p++) v[p] = cmul_tw(v[p], tw.b[p - 1]);
+    // transpose 2: u2[q][p][m] -> lane (p'' = lane&7, q'' = lane>>3) register j = u2[q''][p''][j]
+    {
+        const int base = (lane >> 3) * kScratchRow + (lane & 7);
+#pragma unroll
+        for (int p = 0; p < 8; p++) scratch[base + 9 * p] = v[p];
+    }
+    wave_lds_sync();
+    {
+        const int base = (lane >> 3) * kScratchRow + 9 * (lane & 7);
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = scratch[base + j];
+    }
+    wave_lds_sync();
+    // pass C
+    dft8_fwd(v);
+}
+
+// canonical r2c split.  in: v[r] = Z[kl + 64 r].  out: v[r] = X[kl + 64 r]; returns X[512] (meaningful on lane 0).
+// Leaves Z in natural order in scratch[0..511].
+__device__ __forceinline__ cf rfft_split(cf (&v)[8], cf* __restrict__ scratch, const cf* __restrict__ t1024,
+                                         int lane)
+{
+    const int kl = kl_of_lane(lane);
+#pragma unroll
+    for (int r = 0; r < 8; r++) scratch[kl + 64 * r] = v[r];
+    wave_lds_sync();
+    cf nyq;
+    {
+        // k = 512: A = B = Z[0]
+        const cf A = scratch[0];
+        const cf E = cf{0.5f * (A.x + A.x), 0.5f * (A.y - A.y)};
+        const cf O = cf{0.5f * (A.x - A.x), 0.5f * (A.y + A.y)};
+        const cf P = cmul_tw(O, t1024[512]);
+        nyq = cf{E.x + P.y, E.y - P.x};
+    }
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int k = kl + 64 * r;
+        const cf A = v[r];
+        const cf B = scratch[(512 - k) & 511];
+        const cf E = cf{0.5f * (A.x + B.x), 0.5f * (A.y - B.y)};
+        const cf O = cf{0.5f * (A.x - B.x), 0.5f * (A.y + B.y)};
+        const cf P = cmul_tw(O, t1024[k]);
+        v[r] = cf{E.x + P.y, E.y - P.x};
+    }
+    wave_lds_sync();
+    return nyq;
+}
+
+// canonical atan2 in turns -> Q0.32
+__device__ __forceinline__ uint32_t atan2_q32(float im, float re)
+{
+    const float ax = __builtin_fabsf(re), ay = __builtin_fabsf(im);
+    const bool sw = ay > ax;
+    const float mx = sw ? ay : ax;
+    const float mn = sw ? ax : ay;
+    const float t = mn / mx; // IEEE-correct division (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt)
+    const float s = t * t;
+    float q = NAE_ATAN_C6;
+    q = __builtin_fmaf(q, s, NAE_ATAN_C5);
+    q = __builtin_fmaf(q, s, NAE_ATAN_C4);
+    q = __builtin_fmaf(q, s, NAE_ATAN_C3);
+    q = __builtin_fmaf(q, s, NAE_ATAN_C2);
+    q = __builtin_fmaf(q, s, NAE_ATAN_C1);
+    q = __builtin_fmaf(q, s, NAE_ATAN_C0);
+    float p = q * t;
+    if (sw) p = 0.25f - p;
+    if (re < 0.0f) p = 0.5f - p;
+    if (im < 0.0f) p = -p;
+    float f = p * 4294967296.0f;
+    if (f >= 2147483648.0f) f -= 4294967296.0f;
+    const int32_t r = (int32_t)__builtin_rintf(f);
+    return (mx > 0.0f) ? (uint32_t)r : 0u;
+}
+
+// strided signal access: element (i) of one (stream, channel) at p[i * fs]
+struct ChanView {
+    const float* p;
+    long long fs;   // frame stride in elements
+    long long len;  // valid sample-frames: indices outside [0, len) read as zero
+};
+
+// load + window one frame in FFT input layout: v[j] = (x[s+2n] w[2n], x[s+2n+1] w[2n+1]), n = lane + 64 j
+__device__ __forceinline__ void load_frame_windowed(cf (&v)[8], const ChanView& in, long long s,
+                                                    const float* __restrict__ hann_lds, int lane)
+{
+    const bool interior = (s >= 0) && (s + NAE_FFT_N <= in.len);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int n2 = 2 * (lane + 64 * j);
+        const long long i0 = s + n2;
+        float x0, x1;
+        if (interior) {
+            if (in.fs == 1) {
+                // 4-byte aligned 8-byte access: fine for global memory on gfx9
+                const f2u t = *reinterpret_cast<const f2u*>(in.p + i0);
+                x0 = t.x; x1 = t.y;
+            } else {
+                x0 = in.p[i0 * in.fs];
+                x1 = in.p[(i0 + 1) * in.fs];
+            }
+        } else {
+            x0 = (i0 >= 0 && i0 < in.len) ? in.p[i0 * in.fs] : 0.0f;
+            x1 = (i0 + 1 >= 0 && i0 + 1 < in.len) ? in.p[(i0 + 1) * in.fs] : 0.0f;
+        }
+        const float2 w = *reinterpret_cast<const float2*>(hann_lds + n2);
+        v[j] = cf{x0 * w.x, x1 * w.y};
+    }
+}
+
+} // namespace nae

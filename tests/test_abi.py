@@ -1,0 +1,75 @@
+"""CPU: the C-ABI library loads and exports every symbol include/nae_gpu.h declares; host-only logic (plans,
+argument validation) behaves; and without a GPU the library fails loudly instead of computing on the CPU."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "nae_gpu.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(nae_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(nae):
+    lib = nae.load_library()
+    declared = header_symbols()
+    assert len(declared) >= 50
+    missing = [s for s in declared if not hasattr(lib, s)]
+    assert not missing, missing
+    assert sorted(nae.EXPORTED_SYMBOLS) == declared      # binding table and header agree
+    assert lib.nae_abi_version() == 1
+
+
+def test_no_cpu_fallback_symbols(nae):
+    """the product library must not link or embed the oracle"""
+    import subprocess
+    out = subprocess.run(["nm", "-D", nae.lib_path()], capture_output=True, text=True).stdout
+    assert "orc_" not in out
+    needed = subprocess.run(["readelf", "-d", nae.lib_path()], capture_output=True, text=True).stdout
+    assert "libamdhip64" in needed and "oracle" not in needed
+    # and nothing in the package imports the oracle
+    pkg = os.path.join(ROOT, "nodey-audio-editor_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp")):
+                src = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "nae_oracle" not in src and "import orc" not in src and "liboracle" not in src, f
+
+
+@pytest.mark.parametrize("rate,pitch,L", [(1.0, 2 ** (3 / 12), 48000), (1.5, 1 / 1.5, 48000), (0.5, 1.0, 1000),
+                                          (1.0, 2 ** (-7 / 12), 480000), (3.0, 1.0, 4096), (1.0, 1.0, 77),
+                                          (1.0, 2 ** (3 / 12), 172800000), (2.0, 0.5, 0)])
+def test_stretch_plan_matches_oracle(nae, rate, pitch, L):
+    pl = nae.Context.stretch_plan(rate, pitch, L)
+    rc, ref = orc.plan(rate, pitch, L)
+    assert rc == 0
+    for f in ("pv_on", "rs_on", "tempo_eff", "rate_eff", "ha_q24", "d0", "step_q32", "out_len", "mid_len", "frames"):
+        assert getattr(pl, f) == getattr(ref, f), f
+    assert list(pl.r_q24) == list(ref.r_q24)
+
+
+def test_stretch_plan_rejects_bad_parameters(nae):
+    for rate, pitch in ((0.0, 1.0), (1.0, 0.0), (-1.0, 1.0), (1.0, 1e6), (1e6, 1.0), (float("nan"), 1.0)):
+        with pytest.raises(nae.NaeError):
+            nae.Context.stretch_plan(rate, pitch, 100)
+
+
+def test_spectrum_frame_count(nae):
+    lib = nae.load_library()
+    for T in (0, 1, 1023, 1024, 1279, 1280, 4096, 480000):
+        assert lib.nae_spectrum_frames(T) == orc.lib().orc_spectrum_frames(T)
+
+
+def test_fails_loudly_without_gpu(nae):
+    lib = nae.load_library()
+    if lib.nae_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(nae.NaeError):
+        nae.Context(0)

@@ -1,0 +1,277 @@
+"""GPU parity, K7 (tempo/pitch) and K8 (FFT spectrum), and the 4-node graph — through the C ABI.
+
+Bars: K8 is bit-exact against the oracle (the phase path is specified to the operation) and <= 1e-4 relative RMS
+against the float64 DFT golden; K7's integer synthesis phases are bit-exact and its samples are within the
+1e-4 RMS tolerance BASELINE.json states for float paths."""
+import numpy as np
+import pytest
+
+import orc
+from conftest import rel_rms
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4  # BASELINE.json north_star: "<= 1e-4 RMS for float mix/resample/FFT"
+
+
+def gpu_spectrum(ctx, nae, x, ch, n_streams=1, planar=False):
+    T = x.size // (ch * n_streams)
+    F = ctx.spectrum_frames(T)
+    d_x, d_o = ctx.array(x), ctx.empty(max(1, n_streams * F * ch * 513))
+    sig = nae.Sig.planar(d_x.ptr, T, ch) if planar else nae.Sig.interleaved(d_x.ptr, T, ch)
+    ctx.spectrum_block(sig, T, ch, n_streams, d_o.ptr, F * ch * 513)
+    out = d_o.download()[: n_streams * F * ch * 513].reshape(n_streams, F, ch, 513)
+    d_x.free(); d_o.free()
+    return out
+
+
+@pytest.mark.parametrize("name", ["tone", "noise", "impulse"])
+def test_k8_spectrum_golden_and_bit_exact(ctx, nae, golden, name):
+    g = golden["spectrum"]
+    x = g[f"{name}_in"]
+    got = gpu_spectrum(ctx, nae, x, 1)[0, :, 0, :]
+    assert rel_rms(got, g[f"{name}_mag"]) <= TOL
+    assert rel_rms(got, g[f"{name}_mag"]) <= 2e-6
+    ref = orc.spectrum(x, 1)[:, 0, :]
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), "spectrum not bit-identical to the oracle"
+
+
+def test_k8_stereo_batched_layouts_and_edges(ctx, nae):
+    n_streams, T = 5, 1024 + 256 * 9 + 77
+    x = orc.fill_uniform(n_streams * T * 2, 31)
+    got = gpu_spectrum(ctx, nae, x, 2, n_streams)
+    for s in range(n_streams):
+        ref = orc.spectrum(x.reshape(n_streams, -1)[s], 2)
+        assert np.array_equal(got[s].view(np.uint32), ref.view(np.uint32)), s
+    # planar source gives the same result
+    xp = np.ascontiguousarray(x.reshape(n_streams, T, 2).transpose(0, 2, 1)).reshape(-1)
+    assert np.array_equal(gpu_spectrum(ctx, nae, xp, 2, n_streams, planar=True), got)
+    # too short: zero frames, nothing launched, no error
+    assert gpu_spectrum(ctx, nae, orc.fill_uniform(2 * 1023, 1), 2).shape == (1, 0, 2, 513)
+    assert gpu_spectrum(ctx, nae, orc.fill_uniform(1024, 1), 1).shape == (1, 1, 1, 513)
+
+
+def test_k8_linearity_at_full_size(ctx, nae):
+    """size-independent property at the C5 per-stream size (10 s): spectrum(2x) == 2*spectrum(x), bit-exact"""
+    T = 480000
+    x = orc.fill_uniform(2 * T, 77)
+    a = gpu_spectrum(ctx, nae, x, 2)
+    b = gpu_spectrum(ctx, nae, (2 * x).astype(np.float32), 2)
+    assert a.shape == (1, 1872, 2, 513)
+    assert np.array_equal((2 * a).astype(np.float32), b)
+    # and a strided sample of frames against the oracle
+    for f in (0, 1, 935, 1871):
+        ref = orc.spectrum(x[2 * 256 * f: 2 * (256 * f + 1024)], 2)[0]
+        assert np.array_equal(a[0, f].view(np.uint32), ref.view(np.uint32))
+
+
+def gpu_stretch(ctx, nae, x, ch, rate, pitch, n_streams=1, planar_in=False, planar_out=False):
+    L = x.size // (ch * n_streams)
+    pl = ctx.stretch_plan(rate, pitch, L)
+    d_x, d_o = ctx.array(x), ctx.empty(max(1, n_streams * pl.out_len * ch))
+    src = nae.Sig.planar(d_x.ptr, L, ch) if planar_in else nae.Sig.interleaved(d_x.ptr, L, ch)
+    dst = nae.Sig.planar(d_o.ptr, pl.out_len, ch) if planar_out else nae.Sig.interleaved(d_o.ptr, pl.out_len, ch)
+    ctx.stretch_block(rate, pitch, src, L, ch, n_streams, dst)
+    out = d_o.download()[: n_streams * pl.out_len * ch]
+    d_x.free(); d_o.free()
+    return out, pl
+
+
+def tone(L, amp=(0.5, 0.25), f=(1000.0, 3300.0)):
+    n = np.arange(L)
+    return sum(a * np.sin(2 * np.pi * fr * n / 48000) for a, fr in zip(amp, f)).astype(np.float32)
+
+
+@pytest.mark.parametrize("rate,pitch", [(1.0, 2 ** (3 / 12)), (1.0, 2 ** (-5 / 12)), (1.5, 1 / 1.5), (0.5, 2.0)])
+def test_k7_integer_phases_bit_exact(ctx, nae, rate, pitch):
+    """the synthesis phase in front of every tile equals the oracle's Q0.32 phase, on NOISE (the chaotic case)"""
+    L, ch = 40000, 2
+    x = orc.fill_uniform(L * ch, 41)
+    d_x = ctx.array(x)
+    got, tile = ctx.debug_pv_tile_phase(rate, pitch, nae.Sig.interleaved(d_x.ptr, L, ch), L, ch, 1)
+    d_x.free()
+    qs = orc.pv_synth_phase(x, ch, rate, pitch)          # [frames, ch, 513]
+    n_tiles = got.shape[2]
+    assert n_tiles >= 2
+    for j in range(n_tiles):
+        for c in range(ch):
+            ref = qs[j * tile - 1, c] if j > 0 else np.zeros(513, np.int32)
+            assert np.array_equal(got[0, c, j], ref), (j, c, int(np.count_nonzero(got[0, c, j] != ref)))
+
+
+@pytest.mark.parametrize("rate,pitch,kind", [(1.0, 2 ** (3 / 12), "tone"), (1.0, 2 ** (3 / 12), "noise"),
+                                             (1.0, 2 ** (-7 / 12), "noise"), (1.5, 1 / 1.5, "tone"),
+                                             (0.6, 1 / 0.6, "noise"), (1.5, 1.0, "noise"), (0.5, 1.0, "tone"),
+                                             (3.0, 1 / 3.0, "noise")])
+def test_k7_stretch_vs_oracle(ctx, nae, rate, pitch, kind):
+    L, ch = 30000, 2
+    if kind == "tone":
+        m = tone(L)
+        x = np.stack([m, 0.5 * m], 1).reshape(-1).astype(np.float32)
+    else:
+        x = orc.fill_uniform(L * ch, 43)
+    got, pl = gpu_stretch(ctx, nae, x, ch, rate, pitch)
+    ref = orc.stretch(x, ch, rate, pitch)
+    assert got.size == ref.size == pl.out_len * ch
+    assert pl.out_len == int(np.floor(L / rate + 0.5))
+    assert np.isfinite(got).all()
+    assert rel_rms(got, ref) <= TOL, rel_rms(got, ref)
+    # worst sample error relative to the signal's RMS stays small too (no isolated garbage)
+    assert np.abs(got - ref).max() <= 1e-3 * np.sqrt(np.mean(ref.astype(np.float64) ** 2))
+
+
+def test_k7_golden_regression_and_mono(ctx, nae, golden):
+    g = golden["k7_regression"]
+    for name in ("pitch_up3", "tempo_1p5", "rate_0p8"):
+        rate, pitch = g[name + "_params"]
+        got, _ = gpu_stretch(ctx, nae, g["in"], 1, float(rate), float(pitch))
+        assert rel_rms(got, g[name]) <= TOL, name
+
+
+def test_k7_identity_and_layouts(ctx, nae):
+    L, ch = 5000, 2
+    x = orc.fill_uniform(L * ch, 45)
+    got, _ = gpu_stretch(ctx, nae, x, ch, 1.0, 1.0)
+    assert np.array_equal(got, x)                                      # both stages bypassed: bit copy
+    # planar in / planar out equals interleaved in / interleaved out
+    p = 2 ** (3 / 12)
+    a, pl = gpu_stretch(ctx, nae, x, ch, 1.0, p)
+    xp = np.ascontiguousarray(x.reshape(L, ch).T).reshape(-1)
+    b, _ = gpu_stretch(ctx, nae, xp, ch, 1.0, p, planar_in=True, planar_out=True)
+    assert np.array_equal(b.reshape(ch, pl.out_len).T.reshape(-1), a)
+    # stretch only (no transposer) writes straight to the destination in both layouts
+    a, pl = gpu_stretch(ctx, nae, x, ch, 1.25, 0.8)
+    b, _ = gpu_stretch(ctx, nae, xp, ch, 1.25, 0.8, planar_in=True, planar_out=True)
+    assert np.array_equal(b.reshape(ch, pl.out_len).T.reshape(-1), a)
+
+
+def test_k7_batched_streams_are_independent(ctx, nae):
+    n_streams, L, ch = 9, 12000, 2
+    x = orc.fill_uniform(n_streams * L * ch, 47)
+    p = 2 ** (3 / 12)
+    got, pl = gpu_stretch(ctx, nae, x, ch, 1.0, p, n_streams)
+    got = got.reshape(n_streams, -1)
+    for s in (0, 4, 8):
+        one, _ = gpu_stretch(ctx, nae, x.reshape(n_streams, -1)[s].copy(), ch, 1.0, p)
+        assert np.array_equal(one, got[s]), s
+        assert rel_rms(got[s], orc.stretch(x.reshape(n_streams, -1)[s], ch, 1.0, p)) <= TOL
+
+
+def test_k7_edge_lengths(ctx, nae):
+    p = 2 ** (3 / 12)
+    for L in (0, 1, 255, 256, 1023, 1025):
+        x = orc.fill_uniform(max(L, 1) * 2, 49)[: L * 2]
+        if L == 0:
+            pl = ctx.stretch_plan(1.0, p, 0)
+            assert pl.out_len == 0
+            continue
+        got, pl = gpu_stretch(ctx, nae, x, 2, 1.0, p)
+        ref = orc.stretch(x, 2, 1.0, p)
+        assert got.size == ref.size
+        assert rel_rms(got, ref) <= TOL or np.sqrt(np.mean(ref.astype(np.float64) ** 2)) < 1e-6
+
+
+def test_k7_full_size_properties(ctx, nae):
+    """C3-shaped size-independent checks on a long stream (60 s stereo): length, finiteness, tone lands on pitch,
+    and time-shift invariance of the tiling (prefix of the long run == the run on the prefix, away from the end)."""
+    L, ch = 60 * 48000, 2
+    m = tone(L)
+    x = np.stack([m, m], 1).reshape(-1).astype(np.float32)
+    p = 2 ** (3 / 12)
+    got, pl = gpu_stretch(ctx, nae, x, ch, 1.0, p)
+    assert pl.out_len == L and np.isfinite(got).all()
+    seg = got.reshape(L, ch)[48000 * 20: 48000 * 20 + 65536, 0].astype(np.float64)
+    sp = np.abs(np.fft.rfft(seg * np.hanning(seg.size)))
+    assert abs(np.argmax(sp) * 48000 / seg.size - 1000 * p) < 2.0
+    short, _ = gpu_stretch(ctx, nae, x[: 2 * 200000].copy(), ch, 1.0, p)
+    assert rel_rms(got[: 2 * 150000], short[: 2 * 150000]) <= 1e-6
+    # against the oracle on the first 2 s
+    ref = orc.stretch(x[: 2 * 200000], ch, 1.0, p)
+    assert rel_rms(got[: 2 * 96000], ref[: 2 * 96000]) <= TOL
+
+
+def test_graph4_matches_node_by_node_oracle(ctx, nae):
+    """input -> mix(2) -> pitch -> spectrum on 3 streams with a shared second input"""
+    n_streams, S = 3, 20000
+    a = orc.fill_uniform(n_streams * S * 2, 51)
+    b = orc.fill_uniform(S * 2, 52)
+    p = 2 ** (3 / 12)
+    pl = ctx.stretch_plan(1.0, p, S)
+    F = ctx.spectrum_frames(pl.out_len)
+    d_a, d_b = ctx.array(a), ctx.array(b)
+    d_mix, d_pitch, d_spec = ctx.empty(n_streams * S * 2), ctx.empty(n_streams * pl.out_len * 2), ctx.empty(n_streams * F * 2 * 513)
+    g = nae.Graph4()
+    g.in_a = nae.Sig.interleaved(d_a.ptr, S, 2)
+    g.in_b = nae.Sig.interleaved(d_b.ptr, S, 2, shared=True)
+    g.vol_a, g.vol_b = 0.5, 0.5
+    g.mix_out = nae.Sig.planar(d_mix.ptr, S, 2)
+    g.rate, g.pitch = 1.0, p
+    g.pitch_out = nae.Sig.interleaved(d_pitch.ptr, pl.out_len, 2)
+    g.spec_out, g.spec_stream_stride = d_spec.ptr, F * 2 * 513
+    g.S, g.n_streams = S, n_streams
+    ctx.graph4(g)
+    mix, pitch, spec = d_mix.download(), d_pitch.download(), d_spec.download()
+    for s in range(n_streams):
+        xs = a.reshape(n_streams, S, 2)[s]
+        L, R = orc.amix([xs[:, 0], b[0::2]], [xs[:, 1], b[1::2]], [0.5, 0.5])
+        m = mix.reshape(n_streams, 2, S)[s]
+        assert np.array_equal(m[0], L) and np.array_equal(m[1], R)                         # mix: bit-exact
+        ref_p = orc.stretch(np.stack([L, R], 1).reshape(-1), 2, 1.0, p)
+        got_p = pitch.reshape(n_streams, -1)[s]
+        assert rel_rms(got_p, ref_p) <= TOL                                                # pitch: tolerance
+        ref_s = orc.spectrum(got_p, 2)                                                     # spectrum of what the GPU fed it
+        assert np.array_equal(spec.reshape(n_streams, F, 2, 513)[s].view(np.uint32), ref_s.view(np.uint32))
+        assert rel_rms(spec.reshape(n_streams, F, 2, 513)[s], orc.spectrum(ref_p, 2)) <= TOL  # end to end
+    for d in (d_a, d_b, d_mix, d_pitch, d_spec):
+        d.free()
+
+
+def test_streaming_handles(ctx, nae):
+    import ctypes as C
+    lib = ctx.lib
+    L, ch = 20000, 2
+    x = orc.fill_uniform(L * ch, 61)
+    p = 2 ** (3 / 12)
+    # --- stretch: put in uneven chunks (host), flush, drain in the reference's chunk sizes
+    h = C.c_void_p()
+    assert lib.nae_stretch_create(ctx.h, 48000, ch, 1.0, p, C.byref(h)) == 0
+    pos = 0
+    for n in (1152, 4096, 37, 9000, L):
+        n = min(n, L - pos)
+        chunk = np.ascontiguousarray(x[pos * ch:(pos + n) * ch])
+        assert lib.nae_stretch_put_host(h, chunk.ctypes.data, n) == 0
+        pos += n
+    assert lib.nae_stretch_flush(h) == 0
+    outs = []
+    while lib.nae_stretch_available(h):
+        buf = np.empty(3456 * ch, np.float32)
+        got = C.c_size_t()
+        assert lib.nae_stretch_receive_host(h, buf.ctypes.data, 3456, C.byref(got)) == 0
+        outs.append(buf[: got.value * ch])
+    assert lib.nae_stretch_destroy(h) == 0
+    y = np.concatenate(outs)
+    blk, _ = gpu_stretch(ctx, nae, x, ch, 1.0, p)
+    assert np.array_equal(y, blk)
+    assert lib.nae_stretch_create(ctx.h, 96000, ch, 1.0, p, C.byref(h)) == -2     # audio-velocity.cpp:371-379
+    # --- spectrum: chunked puts give the same frames as the block call
+    hs = C.c_void_p()
+    assert lib.nae_spectrum_create(ctx.h, 1024, 256, ch, C.byref(hs)) == 0
+    d_x = ctx.array(x)
+    frames = []
+    pos = 0
+    for n in (500, 1000, 3000, 1, 255, L):
+        n = min(n, L - pos)
+        assert lib.nae_spectrum_put(hs, d_x.at(pos * ch), n) == 0
+        pos += n
+        k = lib.nae_spectrum_available(hs)
+        if k:
+            d_o = ctx.empty(k * ch * 513)
+            got = C.c_size_t()
+            assert lib.nae_spectrum_receive(hs, d_o.ptr, k, C.byref(got)) == 0 and got.value == k
+            ctx.sync()
+            frames.append(d_o.download().reshape(k, ch, 513))
+            d_o.free()
+    assert lib.nae_spectrum_destroy(hs) == 0
+    d_x.free()
+    allf = np.concatenate(frames)
+    assert np.array_equal(allf, gpu_spectrum(ctx, nae, x, ch)[0])
