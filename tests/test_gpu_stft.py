@@ -231,7 +231,7 @@ def test_streaming_handles(ctx, nae):
     lib = ctx.lib
     L, ch = 20000, 2
     x = orc.fill_uniform(L * ch, 61)
-    p = 2 ** (3 / 12)
+    p = float(np.float32(2 ** (3 / 12)))   # the SoundTouch-shaped API takes float parameters (setPitch(float))
     # --- stretch: put in uneven chunks (host), flush, drain in the reference's chunk sizes
     h = C.c_void_p()
     assert lib.nae_stretch_create(ctx.h, 48000, ch, 1.0, p, C.byref(h)) == 0
