@@ -146,6 +146,7 @@ def main():
         "pv_scan_kernel": 0.0,
         "pv_synth_kernel": 8.0 * sf + 8.0 * sf * mid_ratio,   # input once + stretched signal once
         "resample_kernel": 8.0 * sf * mid_ratio + 8.0 * sf,   # stretched signal once + output once
+        "resample_tile_kernel": 8.0 * sf * mid_ratio + 8.0 * sf,
         "spectrum_kernel": 8.0 * sf + 2 * BINS * 4.0 * n_streams * F,   # 24.03 B per sample-frame
     }
     roofline = None

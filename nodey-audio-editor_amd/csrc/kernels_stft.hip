@@ -20,7 +20,7 @@ namespace nae {
 constexpr int kWaves = 8;                        // waves per workgroup
 constexpr int kThreads = kWaves * 64;
 constexpr int kT1024Pad = kPhasePad;             // 513 entries, padded to 520
-constexpr size_t kLdsTables = NAE_FFT_N * sizeof(float) + kT1024Pad * sizeof(cf);
+constexpr size_t kLdsTables = NAE_FFT_N * sizeof(float) + kT1024Pad * sizeof(cf) + 64 * sizeof(cf);
 constexpr size_t kLdsPerWaveSpec = kScratchCf * sizeof(cf);
 constexpr size_t kLdsPerWavePv = kScratchCf * sizeof(cf) + kRingFloats * sizeof(float);
 
@@ -29,9 +29,14 @@ struct Tables { const cf* w512; const cf* t1024; const float* hann; };
 struct LdsLayout {
     float* hann;
     cf* t1024;
+    cf* w64;       // [m][p] = W512^(8 m p)
     cf* scratch;   // this wave's
     float* ring;   // this wave's (pv only)
 };
+
+// wave index as a SCALAR: hipcc cannot prove threadIdx.x >> 6 wave-uniform, and everything derived from it
+// (stream / tile / frame addresses) would otherwise be carried in VGPRs with 64-bit vector address math
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
 template <bool kRing>
 __device__ __forceinline__ LdsLayout lds_setup(const Tables& tb)
@@ -40,11 +45,13 @@ __device__ __forceinline__ LdsLayout lds_setup(const Tables& tb)
     LdsLayout L;
     L.hann = reinterpret_cast<float*>(smem);
     L.t1024 = reinterpret_cast<cf*>(smem + NAE_FFT_N * sizeof(float));
-    unsigned char* wave_base = smem + kLdsTables + (threadIdx.x >> 6) * (kRing ? kLdsPerWavePv : kLdsPerWaveSpec);
+    L.w64 = L.t1024 + kT1024Pad;
+    unsigned char* wave_base = smem + kLdsTables + wave_id() * (kRing ? kLdsPerWavePv : kLdsPerWaveSpec);
     L.scratch = reinterpret_cast<cf*>(wave_base);
     L.ring = reinterpret_cast<float*>(wave_base + kScratchCf * sizeof(cf));
     for (int i = threadIdx.x; i < NAE_FFT_N; i += kThreads) L.hann[i] = tb.hann[i];
     for (int i = threadIdx.x; i < NAE_FFT_BINS; i += kThreads) L.t1024[i] = tb.t1024[i];
+    if (threadIdx.x < 64) L.w64[threadIdx.x] = tb.w512[8 * (threadIdx.x >> 3) * (threadIdx.x & 7)];
     __syncthreads();
     return L;
 }
@@ -53,22 +60,23 @@ struct SigViewD { const float* base; long long ss, cs, fs; };
 
 // ------------------------------------------------------------------------------------------------ K8
 // one wave per (stream, frame); channels looped so an interleaved source is fetched by one wave
-__global__ __launch_bounds__(kThreads) void spectrum_kernel(SigViewD src, long long T, int ch, long long n_frames,
+template <bool kUnit>
+__global__ __launch_bounds__(kThreads, 4) void spectrum_kernel(SigViewD src, long long T, int ch, long long n_frames,
                                                            long long n_items, float* __restrict__ dst,
                                                            long long dst_ss, Tables tb)
 {
     LdsLayout L = lds_setup<false>(tb);
     const int lane = threadIdx.x & 63;
-    const long long item = (long long)blockIdx.x * kWaves + (threadIdx.x >> 6);
+    const long long item = (long long)blockIdx.x * kWaves + wave_id();
     if (item >= n_items) return;
     const long long s = item / n_frames, f = item % n_frames;
     FftTw tw;
-    load_fft_tw(tw, tb.w512, lane);
+    load_fft_tw(tw, tb.w512, L.w64, lane);
     const int kl = kl_of_lane(lane);
     for (int c = 0; c < ch; c++) {
         ChanView in{src.base + s * src.ss + c * src.cs, src.fs, T};
         cf v[8];
-        load_frame_windowed(v, in, f * NAE_HOP, L.hann, lane);
+        load_frame_windowed<kUnit>(v, in, f * NAE_HOP, L.hann, lane);
         fft512_fwd(v, L.scratch, tw, lane);
         const cf nyq = rfft_split(v, L.scratch, L.t1024, lane);
         float* o = dst + s * dst_ss + (f * ch + c) * NAE_FFT_BINS;
@@ -97,10 +105,11 @@ __device__ __forceinline__ long long frame_start(const PvParams& p, long long f)
 }
 
 // analysis of one frame: windowed load, FFT, split.  X[k] for k = kl+64r in v, X[512] returned.
+template <bool kUnit>
 __device__ __forceinline__ cf analyse(cf (&v)[8], const ChanView& in, long long s, const LdsLayout& L,
                                       const FftTw& tw, int lane)
 {
-    load_frame_windowed(v, in, s, L.hann, lane);
+    load_frame_windowed<kUnit>(v, in, s, L.hann, lane);
     fft512_fwd(v, L.scratch, tw, lane);
     return rfft_split(v, L.scratch, L.t1024, lane);
 }
@@ -128,12 +137,13 @@ __device__ __forceinline__ void phase_inc(const uint32_t (&qa)[9], const uint32_
 }
 
 // pass 1: per-tile sum of phase increments.  sums[(sc * n_tiles + tile) * 520 + k]
-__global__ __launch_bounds__(kThreads) void pv_phase_kernel(SigViewD src, PvParams p, long long n_items,
-                                                           uint32_t* __restrict__ sums, Tables tb)
+template <bool kUnit>
+__global__ __launch_bounds__(kThreads, 4) void pv_phase_kernel(SigViewD src, PvParams p, long long n_items,
+                                                              uint32_t* __restrict__ sums, Tables tb)
 {
     LdsLayout L = lds_setup<false>(tb);
     const int lane = threadIdx.x & 63;
-    const long long item = (long long)blockIdx.x * kWaves + (threadIdx.x >> 6);
+    const long long item = (long long)blockIdx.x * kWaves + wave_id();
     if (item >= n_items) return;
     const long long sc = item / p.n_tiles;
     const int tile = (int)(item % p.n_tiles);
@@ -141,7 +151,7 @@ __global__ __launch_bounds__(kThreads) void pv_phase_kernel(SigViewD src, PvPara
     const int c = (int)(sc % p.ch);
     ChanView in{src.base + s_idx * src.ss + c * src.cs, src.fs, p.in_len};
     FftTw tw;
-    load_fft_tw(tw, tb.w512, lane);
+    load_fft_tw(tw, tb.w512, L.w64, lane);
     const int kl = kl_of_lane(lane);
 
     const long long f0 = (long long)tile * p.tile;
@@ -150,29 +160,23 @@ __global__ __launch_bounds__(kThreads) void pv_phase_kernel(SigViewD src, PvPara
 
     uint32_t acc[9], qp[9], qa[9];
 #pragma unroll
-    for (int r = 0; r < 9; r++) acc[r] = 0;
+    for (int r = 0; r < 9; r++) { acc[r] = 0; qp[r] = 0; }
     cf v[8];
-    long long f = f0;
-    long long s_prev;
-    if (f0 == 0) {
-        s_prev = frame_start(p, 0);
-        const cf nyq = analyse(v, in, s_prev, L, tw, lane);
-        phases_of(v, nyq, qp);
-#pragma unroll
-        for (int r = 0; r < 9; r++) acc[r] = qp[r]; // the "increment" of frame 0 is its analysis phase
-        f = 1;
-    } else {
-        s_prev = frame_start(p, f0 - 1);
-        const cf nyq = analyse(v, in, s_prev, L, tw, lane);
-        phases_of(v, nyq, qp);
-    }
-    for (; f < f1; f++) {
+    long long s_prev = 0;
+    // one analysis call site: frame f0-1 only primes qp (its increment belongs to the previous tile)
+#pragma unroll 1
+    for (long long f = (f0 > 0 ? f0 - 1 : 0); f < f1; f++) {
         const long long s = frame_start(p, f);
-        const cf nyq = analyse(v, in, s, L, tw, lane);
+        const cf nyq = analyse<kUnit>(v, in, s, L, tw, lane);
         phases_of(v, nyq, qa);
-        const unsigned d = (unsigned)(s - s_prev);
-        const unsigned R = (d == (unsigned)p.d0) ? p.r_q24_0 : p.r_q24_1;
-        phase_inc(qa, qp, acc, kl, d, R);
+        if (f == 0) {
+#pragma unroll
+            for (int r = 0; r < 9; r++) acc[r] = qa[r]; // the "increment" of frame 0 is its analysis phase
+        } else if (f >= f0) {
+            const unsigned d = (unsigned)(s - s_prev);
+            const unsigned R = (d == (unsigned)p.d0) ? p.r_q24_0 : p.r_q24_1;
+            phase_inc(qa, qp, acc, kl, d, R);
+        }
 #pragma unroll
         for (int r = 0; r < 9; r++) qp[r] = qa[r];
         s_prev = s;
@@ -202,13 +206,14 @@ __global__ void pv_scan_kernel(uint32_t* __restrict__ sums, long long n_sc, int 
 struct OutViewD { float* base; long long ss, cs, fs; };
 
 // pass 3: synthesis of one tile of output hop blocks [tile*T, (tile+1)*T)
-__global__ __launch_bounds__(kThreads) void pv_synth_kernel(SigViewD src, PvParams p, long long n_items,
-                                                           const uint32_t* __restrict__ base_phase, OutViewD out,
-                                                           Tables tb)
+template <bool kUnit>
+__global__ __launch_bounds__(kThreads, 4) void pv_synth_kernel(SigViewD src, PvParams p, long long n_items,
+                                                              const uint32_t* __restrict__ base_phase, OutViewD out,
+                                                              Tables tb)
 {
     LdsLayout L = lds_setup<true>(tb);
     const int lane = threadIdx.x & 63;
-    const long long item = (long long)blockIdx.x * kWaves + (threadIdx.x >> 6);
+    const long long item = (long long)blockIdx.x * kWaves + wave_id();
     if (item >= n_items) return;
     const long long sc = item / p.n_tiles;
     const int tile = (int)(item % p.n_tiles);
@@ -216,8 +221,9 @@ __global__ __launch_bounds__(kThreads) void pv_synth_kernel(SigViewD src, PvPara
     const int c = (int)(sc % p.ch);
     ChanView in{src.base + s_idx * src.ss + c * src.cs, src.fs, p.in_len};
     float* optr = out.base + s_idx * out.ss + c * out.cs;
+    const bool out_vec = (out.fs == 1) && ((reinterpret_cast<uintptr_t>(optr) & 15) == 0); // wave-uniform
     FftTw tw;
-    load_fft_tw(tw, tb.w512, lane);
+    load_fft_tw(tw, tb.w512, L.w64, lane);
     const int kl = kl_of_lane(lane);
 
     const long long b0 = (long long)tile * p.tile;          // first output block == first frame of the tile
@@ -225,102 +231,111 @@ __global__ __launch_bounds__(kThreads) void pv_synth_kernel(SigViewD src, PvPara
     if (f_end > p.frames) f_end = p.frames;
     const long long b_end = b0 + p.tile;
 
-    uint32_t qs[9], qp[9], qa[9];
+    uint32_t qs[9], qp[9];
     {
         const uint32_t* bp = base_phase + item * kT1024Pad;
 #pragma unroll
-        for (int r = 0; r < 8; r++) qs[r] = bp[kl + 64 * r];
+        for (int r = 0; r < 8; r++) { qs[r] = bp[kl + 64 * r]; qp[r] = 0; }
         qs[8] = bp[512];
+        qp[8] = 0;
     }
     cf v[8];
     long long s_prev = 0;
-    if (b0 > 0) {
-        s_prev = frame_start(p, b0 - 1);
-        const cf nyq = analyse(v, in, s_prev, L, tw, lane);
-        phases_of(v, nyq, qp);
-    }
-    for (long long f = b0; f < f_end; f++) {
+    // Each frame is two half-steps around ONE inlined FFT (a second inlined copy costs ~45 VGPRs):
+    //   half 0: windowed frame -> FFT -> split, phases, phase advance, synthesis spectrum, c2r pre-twiddle
+    //   half 1: conj(Z) -> FFT -> windowed overlap-add, emit the completed hop block
+    // Frame b0-1 (when it exists) only primes qp.
+#pragma unroll 1
+    for (long long f = (b0 > 0 ? b0 - 1 : 0); f < f_end; f++) {
         const long long s = frame_start(p, f);
-        const cf nyq = analyse(v, in, s, L, tw, lane);
-        phases_of(v, nyq, qa);
-        if (f == 0) {
+        load_frame_windowed<kUnit>(v, in, s, L.hann, lane);
+#pragma unroll 1
+        for (int half = 0; half < 2; half++) {
+            fft512_fwd(v, L.scratch, tw, lane);
+            if (half == 0) {
+                const cf nyq = rfft_split(v, L.scratch, L.t1024, lane);
+                uint32_t qa[9];
+                phases_of(v, nyq, qa);
+                if (f >= b0) {
+                    if (f == 0) {
 #pragma unroll
-            for (int r = 0; r < 9; r++) qs[r] += qa[r];
-        } else {
-            const unsigned d = (unsigned)(s - s_prev);
-            const unsigned R = (d == (unsigned)p.d0) ? p.r_q24_0 : p.r_q24_1;
-            phase_inc(qa, qp, qs, kl, d, R);
-        }
-#pragma unroll
-        for (int r = 0; r < 9; r++) qp[r] = qa[r];
-        s_prev = s;
-
-        // ---- synthesis spectrum Y = |X| e^{2 pi i qs}, written in natural order (tolerance path from here)
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const float mag = __builtin_amdgcn_sqrtf(__builtin_fmaf(v[r].x, v[r].x, v[r].y * v[r].y));
-            const float ph = (float)(int32_t)qs[r] * (1.0f / 4294967296.0f);
-            cf y{mag * __builtin_amdgcn_cosf(ph), mag * __builtin_amdgcn_sinf(ph)};
-            if (r == 0 && lane == 0) y.y = 0.0f; // c2r ignores Im Y[0]
-            L.scratch[kl + 64 * r] = y;
-        }
-        if (lane == 0) {
-            const float mag = __builtin_amdgcn_sqrtf(__builtin_fmaf(nyq.x, nyq.x, nyq.y * nyq.y));
-            const float ph = (float)(int32_t)qs[8] * (1.0f / 4294967296.0f);
-            L.scratch[512] = cf{mag * __builtin_amdgcn_cosf(ph), 0.0f};
-        }
-        wave_lds_sync();
-        // ---- c2r pre-twiddle into FFT input layout, conjugated (inverse = conj(FFT(conj Z)) / 512)
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const int k = lane + 64 * r;
-            const cf Xk = L.scratch[k], Xm = L.scratch[512 - k];
-            const cf T = L.t1024[k];
-            const cf E{0.5f * (Xk.x + Xm.x), 0.5f * (Xk.y - Xm.y)};
-            const cf D{0.5f * (Xk.x - Xm.x), 0.5f * (Xk.y + Xm.y)};
-            const cf Q{__builtin_fmaf(T.x, D.x, T.y * D.y), __builtin_fmaf(T.x, D.y, -(T.y * D.x))};
-            v[r] = cf{E.x - Q.y, -(E.y + Q.x)};
-        }
-        wave_lds_sync();
-        fft512_fwd(v, L.scratch, tw, lane);
-        // v[r] = conj(z[n]) * 512, n = kl + 64 r  ->  time samples 2n, 2n+1
-        // ---- windowed overlap-add into the 4-block ring
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const int n2 = 2 * (kl + 64 * r);
-            const float2 w = *reinterpret_cast<const float2*>(L.hann + n2);
-            const float y0 = v[r].x * (1.0f / 512.0f) * w.x;
-            const float y1 = -v[r].y * (1.0f / 512.0f) * w.y;
-            const long long blk = f - 3 + (r >> 1);
-            float2* slot = reinterpret_cast<float2*>(L.ring + (int)(blk & 3) * NAE_HOP + (n2 & (NAE_HOP - 1)));
-            if ((r >> 1) == 3) {
-                *slot = float2{y0, y1};            // newest block: first contribution
-            } else {
-                float2 a = *slot;
-                a.x += y0; a.y += y1;
-                *slot = a;
-            }
-        }
-        wave_lds_sync();
-        // ---- block f-3 is complete
-        const long long be = f - 3;
-        if (be >= b0 && be < b_end) {
-            const long long m0 = be * NAE_HOP + 4 * lane;
-            if (m0 < p.mid_len) {
-                const float4 a = *reinterpret_cast<const float4*>(L.ring + (int)(be & 3) * NAE_HOP + 4 * lane);
-                const float o0 = a.x * NAE_OLA_GAIN, o1 = a.y * NAE_OLA_GAIN, o2 = a.z * NAE_OLA_GAIN,
-                            o3 = a.w * NAE_OLA_GAIN;
-                if (out.fs == 1 && m0 + 4 <= p.mid_len && ((reinterpret_cast<uintptr_t>(optr + m0) & 15) == 0)) {
-                    *reinterpret_cast<float4*>(optr + m0) = float4{o0, o1, o2, o3};
-                } else {
-                    if (m0 + 0 < p.mid_len) optr[(m0 + 0) * out.fs] = o0;
-                    if (m0 + 1 < p.mid_len) optr[(m0 + 1) * out.fs] = o1;
-                    if (m0 + 2 < p.mid_len) optr[(m0 + 2) * out.fs] = o2;
-                    if (m0 + 3 < p.mid_len) optr[(m0 + 3) * out.fs] = o3;
+                        for (int r = 0; r < 9; r++) qs[r] += qa[r];
+                    } else {
+                        const unsigned d = (unsigned)(s - s_prev);
+                        const unsigned R = (d == (unsigned)p.d0) ? p.r_q24_0 : p.r_q24_1;
+                        phase_inc(qa, qp, qs, kl, d, R);
+                    }
                 }
+#pragma unroll
+                for (int r = 0; r < 9; r++) qp[r] = qa[r];
+                s_prev = s;
+                if (f < b0) break;
+                // ---- synthesis spectrum Y = |X| e^{2 pi i qs}, natural order (tolerance path from here)
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const float mag = __builtin_amdgcn_sqrtf(__builtin_fmaf(v[r].x, v[r].x, v[r].y * v[r].y));
+                    const float ph = (float)(int32_t)qs[r] * (1.0f / 4294967296.0f);
+                    cf y{mag * __builtin_amdgcn_cosf(ph), mag * __builtin_amdgcn_sinf(ph)};
+                    if (r == 0 && lane == 0) y.y = 0.0f; // c2r ignores Im Y[0]
+                    L.scratch[kl + 64 * r] = y;
+                }
+                if (lane == 0) {
+                    const float mag = __builtin_amdgcn_sqrtf(__builtin_fmaf(nyq.x, nyq.x, nyq.y * nyq.y));
+                    const float ph = (float)(int32_t)qs[8] * (1.0f / 4294967296.0f);
+                    L.scratch[512] = cf{mag * __builtin_amdgcn_cosf(ph), 0.0f};
+                }
+                wave_lds_sync();
+                // ---- c2r pre-twiddle into FFT input layout, conjugated (inverse = conj(FFT(conj Z)) / 512)
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const int k = lane + 64 * r;
+                    const cf Xk = L.scratch[k], Xm = L.scratch[512 - k];
+                    const cf T = L.t1024[k];
+                    const cf E{0.5f * (Xk.x + Xm.x), 0.5f * (Xk.y - Xm.y)};
+                    const cf D{0.5f * (Xk.x - Xm.x), 0.5f * (Xk.y + Xm.y)};
+                    const cf Q{__builtin_fmaf(T.x, D.x, T.y * D.y), __builtin_fmaf(T.x, D.y, -(T.y * D.x))};
+                    v[r] = cf{E.x - Q.y, -(E.y + Q.x)};
+                }
+                wave_lds_sync();
+            } else {
+                // v[r] = conj(z[n]) * 512, n = kl + 64 r  ->  time samples 2n, 2n+1
+                // ---- windowed overlap-add into the 4-block ring
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const int n2 = 2 * (kl + 64 * r);
+                    const float2 w = *reinterpret_cast<const float2*>(L.hann + n2);
+                    const float y0 = v[r].x * (1.0f / 512.0f) * w.x;
+                    const float y1 = -v[r].y * (1.0f / 512.0f) * w.y;
+                    const int blk = (int)((f - 3 + (r >> 1)) & 3);
+                    float2* slot = reinterpret_cast<float2*>(L.ring + blk * NAE_HOP + (n2 & (NAE_HOP - 1)));
+                    if ((r >> 1) == 3) {
+                        *slot = float2{y0, y1};            // newest block: first contribution
+                    } else {
+                        float2 a = *slot;
+                        a.x += y0; a.y += y1;
+                        *slot = a;
+                    }
+                }
+                wave_lds_sync();
+                // ---- block f-3 is complete
+                const long long be = f - 3;
+                if (be >= b0 && be < b_end && be * NAE_HOP < p.mid_len) {
+                    const long long m0 = be * NAE_HOP + 4 * lane;
+                    const float4 a = *reinterpret_cast<const float4*>(L.ring + (int)(be & 3) * NAE_HOP + 4 * lane);
+                    const float o0 = a.x * NAE_OLA_GAIN, o1 = a.y * NAE_OLA_GAIN, o2 = a.z * NAE_OLA_GAIN,
+                                o3 = a.w * NAE_OLA_GAIN;
+                    if (out_vec && (be + 1) * NAE_HOP <= p.mid_len) {
+                        *reinterpret_cast<float4*>(optr + m0) = float4{o0, o1, o2, o3};
+                    } else {
+                        if (m0 + 0 < p.mid_len) optr[(m0 + 0) * out.fs] = o0;
+                        if (m0 + 1 < p.mid_len) optr[(m0 + 1) * out.fs] = o1;
+                        if (m0 + 2 < p.mid_len) optr[(m0 + 2) * out.fs] = o2;
+                        if (m0 + 3 < p.mid_len) optr[(m0 + 3) * out.fs] = o3;
+                    }
+                }
+                wave_lds_sync();
             }
         }
-        wave_lds_sync();
     }
 }
 
@@ -360,6 +375,93 @@ __global__ __launch_bounds__(256) void resample_kernel(SigViewD src, RsParams p,
     }
 }
 
+// tiled rate transposer: a 256-thread workgroup produces kRsOut consecutive output frames of one stream; the
+// source span it needs (kRsOut*rho + 16 samples per channel) is staged once into LDS with 16-byte loads, the
+// 16 taps are read from LDS, and interleaved stereo output leaves as one 8-byte store per frame.
+constexpr int kRsOut = 1024;                     // output frames per workgroup
+constexpr int kRsMaxSpan = 4096 + 32;            // staged source samples per channel (rho <= 4)
+
+__global__ __launch_bounds__(256) void resample_tile_kernel(SigViewD src, RsParams p, const float* __restrict__ tab,
+                                                           OutViewD out, int span_alloc)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char rs_smem[];
+    float* stab = reinterpret_cast<float*>(rs_smem);                           // (PHASES+1) x TAPS
+    float* stage = stab + (NAE_RS_PHASES + 1) * NAE_RS_TAPS;                   // [ch][span_alloc]
+    for (int i = threadIdx.x; i < (NAE_RS_PHASES + 1) * NAE_RS_TAPS; i += 256) stab[i] = tab[i];
+    const long long s = blockIdx.y;
+    const long long j0 = (long long)blockIdx.x * kRsOut;
+    long long j1 = j0 + kRsOut;
+    if (j1 > p.out_len) j1 = p.out_len;
+    // source window [m_lo, m_hi) of this tile, m_lo rounded down to a multiple of 4 samples
+    const unsigned long long lo0 = (unsigned long long)j0 * p.step_q32, hi0 = __umul64hi((unsigned long long)j0, p.step_q32);
+    const unsigned long long lo1 = (unsigned long long)(j1 - 1) * p.step_q32, hi1 = __umul64hi((unsigned long long)(j1 - 1), p.step_q32);
+    const long long idx_first = (long long)((hi0 << 32) | (lo0 >> 32));
+    const long long idx_last = (long long)((hi1 << 32) | (lo1 >> 32));
+    const long long m_lo = (idx_first - (NAE_RS_TAPS / 2 - 1)) & ~3ll;          // floor to 4 (arithmetic on negatives too)
+    const long long m_hi = idx_last + NAE_RS_TAPS / 2 + 1;
+    const int span = (int)(m_hi - m_lo);
+    for (int c = 0; c < p.ch; c++) {
+        const float* v = src.base + s * src.ss + c * src.cs;
+        float* st = stage + c * span_alloc;
+        const bool vec = (src.fs == 1) && ((reinterpret_cast<uintptr_t>(v) & 15) == 0);
+        if (vec) {
+            for (int i = 4 * threadIdx.x; i < span; i += 4 * 256) {
+                const long long m = m_lo + i;
+                float4 x;
+                if (m >= 0 && m + 4 <= p.src_len) x = *reinterpret_cast<const float4*>(v + m);
+                else {
+                    x.x = (m + 0 >= 0 && m + 0 < p.src_len) ? v[m + 0] : 0.0f;
+                    x.y = (m + 1 >= 0 && m + 1 < p.src_len) ? v[m + 1] : 0.0f;
+                    x.z = (m + 2 >= 0 && m + 2 < p.src_len) ? v[m + 2] : 0.0f;
+                    x.w = (m + 3 >= 0 && m + 3 < p.src_len) ? v[m + 3] : 0.0f;
+                }
+                *reinterpret_cast<float4*>(st + i) = x;
+            }
+        } else {
+            for (int i = threadIdx.x; i < span; i += 256) {
+                const long long m = m_lo + i;
+                st[i] = (m >= 0 && m < p.src_len) ? v[m * src.fs] : 0.0f;
+            }
+        }
+    }
+    __syncthreads();
+    const bool out_pair = (p.ch == 2) && (out.cs == 1) && (out.fs == 2) &&
+                          ((reinterpret_cast<uintptr_t>(out.base + s * out.ss) & 7) == 0);
+    for (long long j = j0 + threadIdx.x; j < j1; j += 256) {
+        const unsigned long long lo = (unsigned long long)j * p.step_q32;
+        const unsigned long long hi = __umul64hi((unsigned long long)j, p.step_q32);
+        const long long idx = (long long)((hi << 32) | (lo >> 32));
+        const unsigned frac = (unsigned)lo;
+        const unsigned ph = frac >> 25;
+        const float alpha = (float)(frac & 0x1FFFFFFu) * (1.0f / 33554432.0f);
+        const float4* t0 = reinterpret_cast<const float4*>(stab + ph * NAE_RS_TAPS);
+        const float4* t1 = t0 + NAE_RS_TAPS / 4;
+        float coef[NAE_RS_TAPS];
+#pragma unroll
+        for (int q = 0; q < NAE_RS_TAPS / 4; q++) {
+            const float4 a = t0[q], b = t1[q];
+            coef[4 * q + 0] = a.x + alpha * (b.x - a.x);
+            coef[4 * q + 1] = a.y + alpha * (b.y - a.y);
+            coef[4 * q + 2] = a.z + alpha * (b.z - a.z);
+            coef[4 * q + 3] = a.w + alpha * (b.w - a.w);
+        }
+        const int o = (int)(idx - (NAE_RS_TAPS / 2 - 1) - m_lo);
+        float acc[2] = {0.0f, 0.0f};
+        for (int c = 0; c < p.ch; c++) {
+            const float* st = stage + c * span_alloc + o;
+            float a = 0.0f;
+#pragma unroll
+            for (int i = 0; i < NAE_RS_TAPS; i++) a += coef[i] * st[i];
+            acc[c] = a;
+        }
+        if (out_pair) {
+            *reinterpret_cast<float2*>(out.base + s * out.ss + 2 * j) = float2{acc[0], acc[1]};
+        } else {
+            for (int c = 0; c < p.ch; c++) out.base[s * out.ss + c * out.cs + j * out.fs] = acc[c];
+        }
+    }
+}
+
 } // namespace nae
 
 // ================================================================================================ host side
@@ -385,8 +487,12 @@ int nae_launch_spectrum(nae_ctx* ctx, const nae_sig* src, size_t T, int ch, size
     const unsigned grid = (unsigned)((items + kWaves - 1) / kWaves);
     const size_t lds = kLdsTables + kWaves * kLdsPerWaveSpec;
     Tables tb{ctx->d_w512, ctx->d_t1024, ctx->d_hann};
-    NAE_KLAUNCH(ctx, "spectrum_kernel", spectrum_kernel, dim3(grid), dim3(kThreads), lds, ctx->stream, to_view(src), (long long)T, ch,
-                       (long long)F, items, dst, (long long)dst_stream_stride, tb);
+    if (src->frame_stride == 1)
+        NAE_KLAUNCH(ctx, "spectrum_kernel", (spectrum_kernel<true>), dim3(grid), dim3(kThreads), lds, ctx->stream, to_view(src),
+                    (long long)T, ch, (long long)F, items, dst, (long long)dst_stream_stride, tb);
+    else
+        NAE_KLAUNCH(ctx, "spectrum_kernel", (spectrum_kernel<false>), dim3(grid), dim3(kThreads), lds, ctx->stream, to_view(src),
+                    (long long)T, ch, (long long)F, items, dst, (long long)dst_stream_stride, tb);
     return nae_check(ctx, hipGetLastError(), "spectrum_kernel");
 }
 
@@ -423,8 +529,12 @@ int nae_launch_pv_phase(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig*
     {
         const unsigned grid = (unsigned)((items + kWaves - 1) / kWaves);
         const size_t lds = kLdsTables + kWaves * kLdsPerWaveSpec;
-        NAE_KLAUNCH(ctx, "pv_phase_kernel", pv_phase_kernel, dim3(grid), dim3(kThreads), lds, ctx->stream, to_view(src), p, items,
-                           phase_ws, tb);
+        if (src->frame_stride == 1)
+            NAE_KLAUNCH(ctx, "pv_phase_kernel", (pv_phase_kernel<true>), dim3(grid), dim3(kThreads), lds, ctx->stream,
+                        to_view(src), p, items, phase_ws, tb);
+        else
+            NAE_KLAUNCH(ctx, "pv_phase_kernel", (pv_phase_kernel<false>), dim3(grid), dim3(kThreads), lds, ctx->stream,
+                        to_view(src), p, items, phase_ws, tb);
         int rc = nae_check(ctx, hipGetLastError(), "pv_phase_kernel");
         if (rc) return rc;
     }
@@ -446,8 +556,12 @@ int nae_launch_pv_synth(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig*
     Tables tb{ctx->d_w512, ctx->d_t1024, ctx->d_hann};
     const unsigned grid = (unsigned)((items + kWaves - 1) / kWaves);
     const size_t lds = kLdsTables + kWaves * kLdsPerWavePv;
-    NAE_KLAUNCH(ctx, "pv_synth_kernel", pv_synth_kernel, dim3(grid), dim3(kThreads), lds, ctx->stream, to_view(src), p, items,
-                       phase_ws, to_out(out), tb);
+    if (src->frame_stride == 1)
+        NAE_KLAUNCH(ctx, "pv_synth_kernel", (pv_synth_kernel<true>), dim3(grid), dim3(kThreads), lds, ctx->stream, to_view(src),
+                    p, items, phase_ws, to_out(out), tb);
+    else
+        NAE_KLAUNCH(ctx, "pv_synth_kernel", (pv_synth_kernel<false>), dim3(grid), dim3(kThreads), lds, ctx->stream, to_view(src),
+                    p, items, phase_ws, to_out(out), tb);
     return nae_check(ctx, hipGetLastError(), "pv_synth_kernel");
 }
 
@@ -456,7 +570,13 @@ int nae_launch_resample(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig*
 {
     if (pl->out_len == 0 || n_streams == 0) return NAE_OK;
     RsParams p{pl->step_q32, (long long)src_len, (long long)pl->out_len, ch};
-    const unsigned gx = (unsigned)((pl->out_len + 255) / 256);
+    // tiled kernel while one tile's source span fits the staging buffer (rho <= 4), else the direct kernel
+    const double rho = (double)pl->step_q32 / 4294967296.0;
+    const long long span_need = (long long)(kRsOut * rho) + NAE_RS_TAPS + 8;
+    const bool tiled = span_need <= kRsMaxSpan;
+    const int span_alloc = (int)((span_need + 3) & ~3ll);
+    const size_t lds = ((NAE_RS_PHASES + 1) * NAE_RS_TAPS + (size_t)ch * span_alloc) * sizeof(float);
+    const unsigned gx = tiled ? (unsigned)((pl->out_len + kRsOut - 1) / kRsOut) : (unsigned)((pl->out_len + 255) / 256);
     // blockIdx.y is limited to 65535
     for (size_t s0 = 0; s0 < n_streams; s0 += 65535) {
         const size_t ns = (n_streams - s0 < 65535) ? n_streams - s0 : 65535;
@@ -464,9 +584,13 @@ int nae_launch_resample(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig*
         OutViewD ov = to_out(out);
         sv.base += (long long)s0 * sv.ss;
         ov.base += (long long)s0 * ov.ss;
-        NAE_KLAUNCH(ctx, "resample_kernel", resample_kernel, dim3(gx, (unsigned)ns), dim3(256), 0, ctx->stream, sv, p, (long long)ns,
-                           d_tab, ov);
-        int rc = nae_check(ctx, hipGetLastError(), "resample_kernel");
+        if (tiled)
+            NAE_KLAUNCH(ctx, "resample_tile_kernel", resample_tile_kernel, dim3(gx, (unsigned)ns), dim3(256), lds, ctx->stream,
+                        sv, p, d_tab, ov, span_alloc);
+        else
+            NAE_KLAUNCH(ctx, "resample_kernel", resample_kernel, dim3(gx, (unsigned)ns), dim3(256), 0, ctx->stream, sv, p,
+                        (long long)ns, d_tab, ov);
+        int rc = nae_check(ctx, hipGetLastError(), "resample kernel");
         if (rc) return rc;
     }
     return NAE_OK;

@@ -60,16 +60,15 @@ __device__ __forceinline__ void dft8_fwd(cf (&a)[8])
 
 // per-lane twiddles of the two twiddled passes, loop-invariant across frames
 struct FftTw {
-    cf a[7]; // W512^(lane*q),        q = 1..7
-    cf b[7]; // W512^(8*(lane&7)*p),  p = 1..7
+    cf a[7];        // W512^(lane*q), q = 1..7: 14 VGPRs, loop-invariant
+    const cf* b;    // LDS table [m][p] = W512^(8 m p), 64 entries shared by the workgroup; this lane reads row lane&7
 };
 
-__device__ __forceinline__ void load_fft_tw(FftTw& tw, const cf* __restrict__ w512, int lane)
+__device__ __forceinline__ void load_fft_tw(FftTw& tw, const cf* __restrict__ w512, const cf* w64_lds, int lane)
 {
 #pragma unroll
     for (int q = 1; q < 8; q++) tw.a[q - 1] = w512[lane * q];
-#pragma unroll
-    for (int p = 1; p < 8; p++) tw.b[p - 1] = w512[8 * (lane & 7) * p];
+    tw.b = w64_lds + 8 * (lane & 7);
 }
 
 // bin / packed-sample index held by (lane, register r) after the forward FFT:  k = kl(lane) + 64 r
@@ -95,7 +94,7 @@ __device__ __forceinline__ void fft512_fwd(cf (&v)[8], cf* __restrict__ scratch,
     // pass B
     dft8_fwd(v);
 #pragma unroll
-    for (int p = 1; p < 8; p++) v[p] = cmul_tw(v[p], tw.b[p - 1]);
+    for (int p = 1; p < 8; p++) v[p] = cmul_tw(v[p], tw.b[p]);
     // transpose 2: u2[q][p][m] -> lane (p'' = lane&7, q'' = lane>>3) register j = u2[q''][p''][j]
     {
         const int base = (lane >> 3) * kScratchRow + (lane & 7);
@@ -178,31 +177,43 @@ struct ChanView {
     long long len;  // valid sample-frames: indices outside [0, len) read as zero
 };
 
-// load + window one frame in FFT input layout: v[j] = (x[s+2n] w[2n], x[s+2n+1] w[2n+1]), n = lane + 64 j
+// load + window one frame in FFT input layout: v[j] = (x[s+2n] w[2n], x[s+2n+1] w[2n+1]), n = lane + 64 j.
+// `s` and `in` are wave-uniform, so the interior/boundary choice is a scalar branch and the interior path
+// addresses with a scalar base + 32-bit lane offset.  kUnit: frame stride 1 (planar source) -> 8-byte loads.
+template <bool kUnit>
 __device__ __forceinline__ void load_frame_windowed(cf (&v)[8], const ChanView& in, long long s,
                                                     const float* __restrict__ hann_lds, int lane)
 {
     const bool interior = (s >= 0) && (s + NAE_FFT_N <= in.len);
+    if (interior) {
+        if (kUnit) {
+            const float* base = in.p + s;
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const int n2 = 2 * (lane + 64 * j);
-        const long long i0 = s + n2;
-        float x0, x1;
-        if (interior) {
-            if (in.fs == 1) {
-                // 4-byte aligned 8-byte access: fine for global memory on gfx9
-                const f2u t = *reinterpret_cast<const f2u*>(in.p + i0);
-                x0 = t.x; x1 = t.y;
-            } else {
-                x0 = in.p[i0 * in.fs];
-                x1 = in.p[(i0 + 1) * in.fs];
+            for (int j = 0; j < 8; j++) {
+                const f2u t = *reinterpret_cast<const f2u*>(base + 2 * lane + 128 * j); // 4-byte aligned 8-byte access
+                v[j] = cf{t.x, t.y};
             }
         } else {
-            x0 = (i0 >= 0 && i0 < in.len) ? in.p[i0 * in.fs] : 0.0f;
-            x1 = (i0 + 1 >= 0 && i0 + 1 < in.len) ? in.p[(i0 + 1) * in.fs] : 0.0f;
+            const int fs = (int)in.fs;
+            const float* base = in.p + s * in.fs;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int n2 = 2 * (lane + 64 * j);
+                v[j] = cf{base[n2 * fs], base[(n2 + 1) * fs]};
+            }
         }
-        const float2 w = *reinterpret_cast<const float2*>(hann_lds + n2);
-        v[j] = cf{x0 * w.x, x1 * w.y};
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const long long i0 = s + 2 * (lane + 64 * j);
+            v[j].x = (i0 >= 0 && i0 < in.len) ? in.p[i0 * in.fs] : 0.0f;
+            v[j].y = (i0 + 1 >= 0 && i0 + 1 < in.len) ? in.p[(i0 + 1) * in.fs] : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const float2 w = *reinterpret_cast<const float2*>(hann_lds + 2 * (lane + 64 * j));
+        v[j] = cf{v[j].x * w.x, v[j].y * w.y};
     }
 }
 
