@@ -47,20 +47,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     torch = None
-    if world > 1 or a.gpus > 1:
+    import naeload
+    if world > 1 or a.gpus > 1 or os.environ.get("NAE_FORCE_DIST"):
         # torch first: its bundled libamdhip64.so.7 is then the one HIP runtime of the process (same soname as
         # /opt/rocm's, so libnae_gpu.so binds to it and device pointers are interchangeable)
         import torch
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        nae = naeload.load()
+        from nodey_audio_editor_amd import shard
+        dist = shard.init("nccl", rank, world)               # "nccl" is RCCL on ROCm
         assert world == a.gpus, f"launched {world} ranks for --gpus {a.gpus}"
 
     import numpy as np
-    import naeload
     nae = naeload.load()
+    from nodey_audio_editor_amd import shard
     ctx = nae.Context(local_rank)
     n_streams, S = a.streams, int(round(a.seconds * 48000))
     pitch = 2.0 ** (SEMITONES / 12.0)
@@ -72,7 +72,7 @@ def main():
     d_mix = ctx.empty(n_streams * S * 2)
     d_pitch = ctx.empty(n_streams * pl.out_len * 2)
     d_spec = ctx.empty(n_streams * F * 2 * BINS)
-    first_stream = rank * n_streams                      # stream s of the job lives on rank s // n_streams
+    first_stream, _ = shard.stream_range(rank, n_streams)   # stream s of the job lives on rank s // n_streams
     ctx.fill_uniform(d_a.ptr, S * 2, S * 2, n_streams, first_stream, 0)
     if dist is not None:
         # shared second mix input: generated on rank 0, broadcast over RCCL/xGMI (the only collective)
@@ -80,7 +80,7 @@ def main():
         if rank == 0:
             ctx.fill_uniform(t_b.data_ptr(), S * 2, 0, 1, 0, 1)
             ctx.sync()
-        dist.broadcast(t_b, src=0)
+        shard.broadcast_shared(dist, t_b, 0)
         torch.cuda.synchronize()
         b_ptr = t_b.data_ptr()
     else:
@@ -124,9 +124,7 @@ def main():
         ctx.prof_enable(False)
         kernels = ctx.prof_report()
     if dist is not None:
-        t_el = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
-        elapsed = float(t_el.item())
+        elapsed = shard.max_over_ranks(dist, elapsed, device=f"cuda:{local_rank}")
         dist.barrier()
 
     if rank != 0:
@@ -134,8 +132,7 @@ def main():
             dist.destroy_process_group()
         return
 
-    frames_per_step = world * n_streams * S
-    value = frames_per_step * a.steps / elapsed
+    value = shard.job_throughput(world, n_streams, S, a.steps, elapsed)
 
     # ---- roofline of the dominant kernel: algorithmic (compulsory) bytes of that launch / its mean duration
     sf = n_streams * S                                   # sample-frames one launch covers on this GPU

@@ -1,0 +1,301 @@
+#include "audio-velocity.hpp"
+#include "gpu-context.hpp"
+
+#include <algorithm>
+#include <cmath>
+
+namespace processor
+{
+	namespace
+	{
+		std::vector<infra::Processor::Pin_attribute> io_pins()
+		{
+			return {
+				{"output", "Output", typeid(Audio_stream), false, [] { return std::make_shared<Audio_stream>(); }},
+				{"input", "Input", typeid(Audio_stream), true, [] { return std::make_shared<Audio_stream>(); }}
+			};
+		}
+
+		// construct_audio_frame_float, audio-velocity.cpp:234-263 (time_us is a FLOAT there: 24-bit pts quirk kept)
+		std::shared_ptr<Audio_frame> construct_audio_frame_float(const std::vector<float>& samples, int sample_rate,
+																 int channel_count, float time_us)
+		{
+			auto new_frame = std::make_shared<Audio_frame>();
+			Frame_data* frame = new_frame->data();
+			frame->sample_rate = sample_rate;
+			frame->ch_layout.nb_channels = channel_count;
+			frame->nb_samples = static_cast<int>(samples.size() / channel_count);
+			frame->format = AV_SAMPLE_FMT_FLT;
+			frame->time_base = {1, 1000000};
+			frame->pts = static_cast<int64_t>(time_us);
+			frame_get_buffer(frame, 32);
+			std::copy(samples.begin(), samples.end(), reinterpret_cast<float*>(frame->data[0]));
+			return new_frame;
+		}
+
+		// frame -> device interleaved f32 (extract_samples_interleaved, :150-232, as nae_to_f32_interleaved)
+		float* upload_as_f32(const Frame_data* frame, gpu::Device_buffer& d_raw, gpu::Device_buffer& d_f32)
+		{
+			nae_ctx* ctx = gpu::context();
+			const int ch = frame->ch_layout.nb_channels;
+			const int bps = bytes_per_sample(frame->format);
+			if (bps == 0 || frame->format == AV_SAMPLE_FMT_DBL)
+				throw infra::Processor::Runtime_error(
+					"Unsupported sample format", "The processors do not support the given sample format.",
+					infra::fmt("Sample format: %d", frame->format)
+				);
+			const bool planar = sample_fmt_is_planar(frame->format);
+			const int planes = planar ? ch : 1;
+			const size_t plane_bytes = (size_t)frame->nb_samples * bps * (planar ? 1 : ch);
+			const size_t stride = (plane_bytes + 255) / 256 * 256;
+			auto* raw = static_cast<uint8_t*>(d_raw.reserve(stride * planes));
+			float* out = static_cast<float*>(d_f32.reserve((size_t)frame->nb_samples * ch * sizeof(float)));
+			const void* pl[2] = {raw, raw + stride};
+			for (int p = 0; p < planes; p++) gpu::check(nae_memcpy_h2d(ctx, raw + p * stride, frame->data[p], plane_bytes), "h2d");
+			gpu::check(nae_to_f32_interleaved(ctx, frame->format, pl, frame->nb_samples, ch, out), "nae_to_f32_interleaved");
+			return out;
+		}
+
+		// soundtouch_process_payload, audio-velocity.cpp:265-443, with nae_stretch in SoundTouch's place
+		void stretch_process_payload(
+			const std::map<std::string, std::shared_ptr<infra::Processor::Product>>& input,
+			const std::map<std::string, std::set<std::shared_ptr<infra::Processor::Product>>>& output,
+			const std::atomic<bool>& stop_token, float velocity, float pitch, const std::string& processor_name
+		)
+		{
+			const auto input_item = infra::get_input_item<Audio_stream>(input, "input");
+			const auto output_stream = infra::get_output_item<Audio_stream>(output, "output");
+			if (!input_item.has_value())
+				throw infra::Processor::Runtime_error(
+					processor_name + " has no input",
+					processor_name + " requires an audio stream input to function properly.",
+					"Input item 'input' not found"
+				);
+			Audio_stream& input_stream = input_item.value().get();
+			nae_ctx* ctx = gpu::context();
+			nae_stretch* soundtouch = nullptr;
+			struct Guard { nae_stretch*& h; ~Guard() { if (h) nae_stretch_destroy(h); } } guard{soundtouch};
+			gpu::Device_buffer d_raw, d_f32;
+			bool input_stream_eof = false;
+			const double time_ratio = 1.0f / velocity;
+			int channel_count = 0, sample_rate = 0;
+			double time_seconds = 0.0;
+
+			auto acquire_func = [&](int count)
+			{
+				std::vector<float> output_samples((size_t)count * channel_count);
+				size_t samples_read = 0;
+				gpu::wait(stop_token);
+				gpu::check(nae_stretch_receive_host(soundtouch, output_samples.data(), count, &samples_read), "nae_stretch_receive_host");
+				output_samples.resize(samples_read * channel_count);
+				auto new_frame = construct_audio_frame_float(output_samples, sample_rate, channel_count, (float)(time_seconds * 1000000));
+				time_seconds += double(samples_read) / sample_rate;
+				for (auto& stream : output_stream)
+					while (!stop_token)
+					{
+						if (stream->try_push(new_frame) == channel_op_status::success) break;
+						nae_fiber::this_fiber::yield();
+					}
+			};
+
+			while (!stop_token)
+			{
+				if (!input_stream_eof)
+				{
+					const auto pop_result = input_stream.try_pop();
+					if (!pop_result.has_value())
+					{
+						if (pop_result.error() != channel_op_status::empty)
+							throw infra::Processor::Runtime_error(
+								"Unexpected error when fetching audio frame", processor_name + " encountered an unexpected error.",
+								infra::fmt("Channel fetch error: %d", (int)pop_result.error())
+							);
+						if (input_stream.eof()) input_stream_eof = true;
+					}
+					else
+					{
+						constexpr size_t max_queued_samples = 65536;
+						const Frame_data* frame = pop_result.value()->data();
+						if (soundtouch == nullptr)
+						{
+							if (frame->sample_rate < 8000 || frame->sample_rate > 48000)  // :371-379
+								throw infra::Processor::Runtime_error(
+									"Unsupported sample rate",
+									infra::fmt("%d requires a sample rate between 8000 and 48000 Hz.", frame->sample_rate),
+									infra::fmt("Sample rate: %d", frame->sample_rate)
+								);
+							gpu::check(
+								nae_stretch_create(ctx, frame->sample_rate, frame->ch_layout.nb_channels, velocity, pitch, &soundtouch),
+								"nae_stretch_create"
+							);
+							channel_count = frame->ch_layout.nb_channels;
+							time_seconds = frame->pts * av_q2d(frame->time_base);
+							sample_rate = frame->sample_rate;
+						}
+						while (!stop_token && nae_stretch_available(soundtouch) > max_queued_samples) nae_fiber::this_fiber::yield();
+						float* samples = upload_as_f32(frame, d_raw, d_f32);
+						gpu::check(nae_stretch_put(soundtouch, samples, frame->nb_samples), "nae_stretch_put");
+						gpu::wait(stop_token);  // d_raw / d_f32 are reused for the next frame
+					}
+				}
+				if (soundtouch != nullptr)
+				{
+					if (nae_stretch_available(soundtouch) == 0 && input_stream_eof && false) break;  // (:414 is subsumed by the flush branch)
+					const uint32_t min_samples = time_ratio * 1152;
+					const uint32_t max_samples = time_ratio * 1152 * 3;
+					if (nae_stretch_available(soundtouch) > min_samples)
+						acquire_func((int)std::min<size_t>(nae_stretch_available(soundtouch), max_samples));
+					else if (input_stream_eof)
+					{
+						gpu::check(nae_stretch_flush(soundtouch), "nae_stretch_flush");
+						// the reference emits ONE frame with everything that is left (:427-433); here flush() may release
+						// the whole stream, so it is cut into the same [min, max] chunks the steady state uses
+						while (!stop_token && nae_stretch_available(soundtouch) > 0)
+							acquire_func((int)std::min<size_t>(nae_stretch_available(soundtouch), std::max<uint32_t>(max_samples, 1)));
+						break;
+					}
+				}
+				else if (input_stream_eof)
+					break;
+				nae_fiber::this_fiber::yield();
+			}
+			for (auto& stream : output_stream) stream->set_eof();
+		}
+	}
+
+	// ------------------------------------------------------------------------------------------ Velocity_modifier
+	infra::Processor::Info Velocity_modifier::get_processor_info()
+	{
+		return {"velocity_modifier", "Velocity Modifier", false,
+				[] { return std::unique_ptr<infra::Processor>(new Velocity_modifier); }, "Audio Velocity Modifier (MI355X)"};
+	}
+	std::vector<infra::Processor::Pin_attribute> Velocity_modifier::get_pin_attributes() const { return io_pins(); }
+
+	void Velocity_modifier::process_payload(
+		const std::map<std::string, std::shared_ptr<infra::Processor::Product>>& input,
+		const std::map<std::string, std::set<std::shared_ptr<infra::Processor::Product>>>& output,
+		const std::atomic<bool>& stop_token, std::any&
+	)
+	{
+		stretch_process_payload(input, output, stop_token, velocity, keep_pitch ? 1 / velocity : 1, get_processor_info().display_name);  // :452-459
+	}
+
+	Json::Value Velocity_modifier::serialize() const
+	{
+		Json::Value value;
+		value["velocity"] = velocity;
+		value["keep_pitch"] = keep_pitch;
+		return value;
+	}
+
+	void Velocity_modifier::deserialize(const Json::Value& value)
+	{
+		if (value.isMember("velocity") && value["velocity"].isDouble()) velocity = value["velocity"].asFloat();
+		if (value.isMember("keep_pitch") && value["keep_pitch"].isBool()) keep_pitch = value["keep_pitch"].asBool();
+	}
+
+	// ------------------------------------------------------------------------------------------ Pitch_modifier
+	infra::Processor::Info Pitch_modifier::get_processor_info()
+	{
+		return {"pitch_modifier", "Pitch Modifier", false, [] { return std::unique_ptr<infra::Processor>(new Pitch_modifier); },
+				"Audio Pitch Modifier (MI355X)"};
+	}
+	std::vector<infra::Processor::Pin_attribute> Pitch_modifier::get_pin_attributes() const { return io_pins(); }
+
+	void Pitch_modifier::process_payload(
+		const std::map<std::string, std::shared_ptr<infra::Processor::Product>>& input,
+		const std::map<std::string, std::set<std::shared_ptr<infra::Processor::Product>>>& output,
+		const std::atomic<bool>& stop_token, std::any&
+	)
+	{
+		stretch_process_payload(input, output, stop_token, 1, std::pow(2.0f, pitch / 12.0f), get_processor_info().display_name);  // :469-476
+	}
+
+	Json::Value Pitch_modifier::serialize() const
+	{
+		Json::Value value;
+		value["pitch"] = pitch;
+		return value;
+	}
+	void Pitch_modifier::deserialize(const Json::Value& value)
+	{
+		if (value.isMember("pitch") && value["pitch"].isDouble()) pitch = value["pitch"].asFloat();
+	}
+
+	// ------------------------------------------------------------------------------------------ Audio_spectrum
+	infra::Processor::Info Audio_spectrum::get_processor_info()
+	{
+		return {"audio_spectrum", "FFT Spectrum", false, [] { return std::unique_ptr<infra::Processor>(new Audio_spectrum); },
+				"Hann-windowed 1024-point magnitude spectrum every 256 samples (MI355X)"};
+	}
+	std::vector<infra::Processor::Pin_attribute> Audio_spectrum::get_pin_attributes() const { return io_pins(); }
+
+	void Audio_spectrum::process_payload(
+		const std::map<std::string, std::shared_ptr<infra::Processor::Product>>& input,
+		const std::map<std::string, std::set<std::shared_ptr<infra::Processor::Product>>>& output,
+		const std::atomic<bool>& stop_token, std::any&
+	)
+	{
+		const auto input_item = infra::get_input_item<Audio_stream>(input, "input");
+		const auto output_stream = infra::get_output_item<Audio_stream>(output, "output");
+		if (!input_item.has_value())
+			throw Runtime_error("FFT Spectrum has no input", "FFT Spectrum requires an audio stream input to function properly.", "Input item 'input' not found");
+		Audio_stream& input_stream = input_item.value().get();
+		nae_ctx* ctx = gpu::context();
+		nae_spectrum* spectrum = nullptr;
+		struct Guard { nae_spectrum*& h; ~Guard() { if (h) nae_spectrum_destroy(h); } } guard{spectrum};
+		gpu::Device_buffer d_raw, d_f32, d_out;
+		int ch = 0, sample_rate = 0;
+		double time_seconds = 0.0;
+		std::vector<float> host;
+
+		while (!stop_token)
+		{
+			const auto pop_result = input_stream.try_pop();
+			if (!pop_result.has_value())
+			{
+				if (input_stream.eof()) break;  // a trailing partial window produces no frame
+				nae_fiber::this_fiber::yield();
+				continue;
+			}
+			const Frame_data* frame = pop_result.value()->data();
+			if (spectrum == nullptr)
+			{
+				ch = frame->ch_layout.nb_channels;
+				if (ch != 1 && ch != 2) throw Runtime_error("Invalid channel count", "Only mono and stereo audio are supported.", infra::fmt("Got %d channels", ch));
+				sample_rate = frame->sample_rate;
+				time_seconds = frame->pts * av_q2d(frame->time_base);
+				gpu::check(nae_spectrum_create(ctx, 1024, 256, ch, &spectrum), "nae_spectrum_create");
+			}
+			float* samples = upload_as_f32(frame, d_raw, d_f32);
+			gpu::check(nae_spectrum_put(spectrum, samples, frame->nb_samples), "nae_spectrum_put");
+			const size_t ready = nae_spectrum_available(spectrum);
+			if (ready == 0) { gpu::wait(stop_token); continue; }
+			const size_t rec = (size_t)ch * 513;
+			float* dout = static_cast<float*>(d_out.reserve(ready * rec * sizeof(float)));
+			size_t got = 0;
+			gpu::check(nae_spectrum_receive(spectrum, dout, ready, &got), "nae_spectrum_receive");
+			host.resize(got * rec);
+			gpu::check(nae_memcpy_d2h(ctx, host.data(), dout, host.size() * sizeof(float)), "d2h");
+			gpu::wait(stop_token);
+			for (size_t f = 0; f < got && !stop_token; f++)
+			{
+				auto out = std::make_shared<Audio_frame>();
+				Frame_data* o = out->data();
+				o->format = AV_SAMPLE_FMT_FLTP;
+				o->sample_rate = sample_rate;
+				o->nb_samples = 513;
+				o->ch_layout.nb_channels = ch;
+				o->time_base = {1, 1000000};
+				o->pts = (int64_t)(time_seconds * 1000000);
+				frame_get_buffer(o, 32);
+				for (int c = 0; c < ch; c++)
+					std::copy(host.begin() + (f * ch + c) * 513, host.begin() + (f * ch + c + 1) * 513, reinterpret_cast<float*>(o->data[c]));
+				time_seconds += 256.0 / sample_rate;
+				for (auto& stream : output_stream)
+					while (!stop_token && stream->try_push(out) != channel_op_status::success) nae_fiber::this_fiber::yield();
+			}
+		}
+		for (auto& stream : output_stream) stream->set_eof();
+	}
+}

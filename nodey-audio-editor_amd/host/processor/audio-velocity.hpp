@@ -1,0 +1,67 @@
+// processor/audio-velocity.hpp — GPU drop-ins for processor::Velocity_modifier and processor::Pitch_modifier
+// (/root/reference/include/processor/audio-velocity.hpp, src/processor/audio-velocity.cpp:265-505), plus the
+// FFT spectrum node the reference lists as a feature (README.md:28) but never implemented.
+#pragma once
+#include "audio-stream.hpp"
+
+namespace processor
+{
+	class Velocity_modifier : public infra::Processor
+	{
+		float velocity = 1;
+		bool keep_pitch = false;
+
+	  public:
+
+		static infra::Processor::Info get_processor_info();
+		Processor::Info get_processor_info_non_static() const override { return get_processor_info(); }
+		std::vector<infra::Processor::Pin_attribute> get_pin_attributes() const override;
+		void process_payload(
+			const std::map<std::string, std::shared_ptr<infra::Processor::Product>>& input,
+			const std::map<std::string, std::set<std::shared_ptr<infra::Processor::Product>>>& output,
+			const std::atomic<bool>& stop_token,
+			std::any& user_data
+		) override;
+		Json::Value serialize() const override;            // velocity, keep_pitch (audio-velocity.cpp:479-485)
+		void deserialize(const Json::Value& value) override;  // :487-493
+	};
+
+	class Pitch_modifier : public infra::Processor
+	{
+		float pitch = 0;  // semitones
+
+	  public:
+
+		static infra::Processor::Info get_processor_info();
+		Processor::Info get_processor_info_non_static() const override { return get_processor_info(); }
+		std::vector<infra::Processor::Pin_attribute> get_pin_attributes() const override;
+		void process_payload(
+			const std::map<std::string, std::shared_ptr<infra::Processor::Product>>& input,
+			const std::map<std::string, std::set<std::shared_ptr<infra::Processor::Product>>>& output,
+			const std::atomic<bool>& stop_token,
+			std::any& user_data
+		) override;
+		Json::Value serialize() const override;            // pitch (:495-500)
+		void deserialize(const Json::Value& value) override;  // :502-505
+	};
+
+	// New node (registered as "audio_spectrum"): per channel, Hann-windowed 1024-point r2c magnitude every 256
+	// sample-frames.  Output stays an Audio_stream so the editor's pin type check passes: one FLTP frame per hop with
+	// nb_samples = 513 (bins), plane c = |X_c[k]|, pts = start time of the analysed window.
+	class Audio_spectrum : public infra::Processor
+	{
+	  public:
+
+		static infra::Processor::Info get_processor_info();
+		Processor::Info get_processor_info_non_static() const override { return get_processor_info(); }
+		std::vector<infra::Processor::Pin_attribute> get_pin_attributes() const override;
+		void process_payload(
+			const std::map<std::string, std::shared_ptr<infra::Processor::Product>>& input,
+			const std::map<std::string, std::set<std::shared_ptr<infra::Processor::Product>>>& output,
+			const std::atomic<bool>& stop_token,
+			std::any& user_data
+		) override;
+		Json::Value serialize() const override { return {}; }
+		void deserialize(const Json::Value&) override {}
+	};
+}

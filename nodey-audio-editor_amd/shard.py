@@ -1,0 +1,49 @@
+"""Multi-GPU sharding of independent streams: stream s of the job lives on rank s // per_rank (weak
+scaling: every rank owns the same number of streams), there is no data-path collective, and the only exchange is the
+one-shot broadcast of the shared source buffer from rank 0 at setup (RCCL over xGMI on GPUs, gloo in the CPU tests).
+torch.distributed is plumbing only; nothing here computes audio."""
+from __future__ import annotations
+
+import os
+from typing import Tuple
+
+
+def env_rank_world() -> Tuple[int, int, int]:
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def stream_range(rank: int, per_rank: int) -> Tuple[int, int]:
+    """global stream ids [first, last) owned by `rank`"""
+    return rank * per_rank, (rank + 1) * per_rank
+
+
+def stream_seed(stream: int, input_index: int = 0) -> int:
+    """seed = 0x9E3779B97F4A7C15 * (1 + s) + k  (mod 2^64)"""
+    return (0x9E3779B97F4A7C15 * (1 + stream) + input_index) & 0xFFFFFFFFFFFFFFFF
+
+
+def init(backend: str, rank: int, world: int):
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    return dist
+
+
+def broadcast_shared(dist, tensor, src: int = 0):
+    """the single collective of the path: every rank leaves with rank `src`'s copy of the shared source buffer"""
+    dist.broadcast(tensor, src=src)
+    return tensor
+
+
+def max_over_ranks(dist, seconds: float, device=None) -> float:
+    """elapsed time of the job = slowest rank (bench.py contract)"""
+    import torch
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def job_throughput(world: int, per_rank_streams: int, frames_per_stream: int, steps: int, elapsed_s: float) -> float:
+    """whole-job sample-frames/s: all ranks' units over the slowest rank's time"""
+    return world * per_rank_streams * frames_per_stream * steps / elapsed_s

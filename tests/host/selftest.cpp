@@ -1,0 +1,435 @@
+// selftest.cpp — drives the host mirror (nodey-audio-editor_amd/host) the way the reference's Runner drives its
+// processors: one fiber per node, bounded Audio_streams between them.  `selftest cpu` checks the scheduler / stream /
+// registry / error plumbing without a GPU; `selftest gpu` runs real graphs through the GPU processors and compares
+// with the CPU oracle (this file is test code: linking the oracle here is allowed).
+#include "infra/runner.hpp"
+#include "processor/audio-mix.hpp"
+#include "processor/audio-velocity.hpp"
+#include "processor/audio-vol.hpp"
+#include "../../oracle/nae_oracle.h"
+
+#include <cmath>
+#include <cstring>
+#include <iostream>
+
+using namespace processor;
+using infra::Runner;
+
+static int failures = 0;
+#define CHECK(cond, msg)                                                          \
+	do {                                                                          \
+		if (!(cond)) { std::cout << "FAIL " << __LINE__ << ": " << msg << "\n"; failures++; } \
+	} while (0)
+
+// ---- test-only nodes
+class Test_source : public infra::Processor
+{
+  public:
+
+	std::vector<float> samples;  // interleaved
+	int ch = 2, frame_size = 1152, format = AV_SAMPLE_FMT_FLT, sample_rate = 48000;
+	double start_seconds = 0.0;
+
+	static Info get_processor_info() { return {"test_source", "Test Source", false, [] { return std::unique_ptr<Processor>(new Test_source); }, ""}; }
+	Info get_processor_info_non_static() const override { return get_processor_info(); }
+	std::vector<Pin_attribute> get_pin_attributes() const override
+	{
+		return {{"output", "Output", typeid(Audio_stream), false, [] { return std::make_shared<Audio_stream>(); }}};
+	}
+	Json::Value serialize() const override { return {}; }
+	void deserialize(const Json::Value&) override {}
+	void process_payload(const std::map<std::string, std::shared_ptr<Product>>&,
+						 const std::map<std::string, std::set<std::shared_ptr<Product>>>& output,
+						 const std::atomic<bool>& stop_token, std::any&) override
+	{
+		const auto outs = infra::get_output_item<Audio_stream>(output, "output");
+		const size_t total = samples.size() / ch;
+		for (size_t pos = 0; pos < total && !stop_token; pos += frame_size)
+		{
+			const int n = (int)std::min<size_t>(frame_size, total - pos);
+			auto frame = std::make_shared<Audio_frame>();
+			Frame_data* f = frame->data();
+			f->format = format;
+			f->sample_rate = sample_rate;
+			f->nb_samples = n;
+			f->ch_layout.nb_channels = ch;
+			f->time_base = {1, 1000000};
+			f->pts = (int64_t)((start_seconds + double(pos) / sample_rate) * 1000000);
+			frame_get_buffer(f, 32);
+			const float* src = samples.data() + pos * ch;
+			if (format == AV_SAMPLE_FMT_FLT) std::memcpy(f->data[0], src, (size_t)n * ch * sizeof(float));
+			else if (format == AV_SAMPLE_FMT_FLTP)
+				for (int c = 0; c < ch; c++)
+					for (int i = 0; i < n; i++) reinterpret_cast<float*>(f->data[c])[i] = src[i * ch + c];
+			else if (format == AV_SAMPLE_FMT_S16)
+				for (int i = 0; i < n * ch; i++) reinterpret_cast<int16_t*>(f->data[0])[i] = (int16_t)std::lrintf(src[i] * 32767.0f);
+			for (auto& o : outs)
+				while (!stop_token && o->try_push(frame) != channel_op_status::success) nae_fiber::this_fiber::yield();
+		}
+		for (auto& o : outs) o->set_eof();
+	}
+};
+
+class Test_sink : public infra::Processor
+{
+  public:
+
+	std::vector<std::shared_ptr<const Audio_frame>> frames;
+	size_t max_fill = 0;
+
+	static Info get_processor_info() { return {"test_sink", "Test Sink", false, [] { return std::unique_ptr<Processor>(new Test_sink); }, ""}; }
+	Info get_processor_info_non_static() const override { return get_processor_info(); }
+	std::vector<Pin_attribute> get_pin_attributes() const override
+	{
+		return {{"input", "Input", typeid(Audio_stream), true, [] { return std::make_shared<Audio_stream>(); }}};
+	}
+	Json::Value serialize() const override { return {}; }
+	void deserialize(const Json::Value&) override {}
+	void process_payload(const std::map<std::string, std::shared_ptr<Product>>& input,
+						 const std::map<std::string, std::set<std::shared_ptr<Product>>>&, const std::atomic<bool>& stop_token,
+						 std::any&) override
+	{
+		auto in = infra::get_input_item<Audio_stream>(input, "input");
+		if (!in.has_value()) throw Runtime_error("sink has no input", "", "");
+		Audio_stream& s = in.value().get();
+		int lazy = 0;
+		while (!stop_token)
+		{
+			max_fill = std::max(max_fill, s.buffered_count());
+			if ((++lazy & 3) != 0) { nae_fiber::this_fiber::yield(); continue; }  // a slow consumer: forces back-pressure
+			auto r = s.try_pop();
+			if (!r.has_value())
+			{
+				if (s.eof()) break;
+				nae_fiber::this_fiber::yield();
+				continue;
+			}
+			frames.push_back(r.value());
+		}
+	}
+	std::vector<float> interleaved() const  // FLT frames concatenated
+	{
+		std::vector<float> out;
+		for (auto& f : frames)
+		{
+			const Frame_data* d = f->data();
+			const float* p = reinterpret_cast<const float*>(d->data[0]);
+			out.insert(out.end(), p, p + (size_t)d->nb_samples * d->ch_layout.nb_channels);
+		}
+		return out;
+	}
+};
+
+static std::vector<float> uniform(size_t n, uint64_t seed)
+{
+	std::vector<float> v(n);
+	orc_fill_uniform(v.data(), n, seed);
+	return v;
+}
+
+static double rel_rms(const std::vector<float>& a, const std::vector<float>& b)
+{
+	if (a.size() != b.size()) return 1e9;
+	double e = 0, r = 0;
+	for (size_t i = 0; i < a.size(); i++) { e += (double(a[i]) - b[i]) * (double(a[i]) - b[i]); r += double(b[i]) * b[i]; }
+	return std::sqrt(e / std::max(r, 1e-300));
+}
+
+// ------------------------------------------------------------------------------------------------ CPU-only checks
+static void test_streams_and_scheduler()
+{
+	Audio_stream s;
+	auto f = std::make_shared<Audio_frame>();
+	for (int i = 0; i < 16; i++) CHECK(s.try_push(f) == channel_op_status::success, "push " << i);
+	CHECK(s.try_push(f) == channel_op_status::full, "17th push must report full (capacity 16, config.hpp:53)");
+	CHECK(s.buffered_count() == 16, "fill counter");
+	for (int i = 0; i < 16; i++) CHECK(s.try_pop().has_value(), "pop " << i);
+	auto e = s.try_pop();
+	CHECK(!e.has_value() && e.error() == channel_op_status::empty, "empty status");
+	CHECK(!s.eof(), "eof flag is separate from the queue");
+	s.set_eof();
+	CHECK(s.eof(), "set_eof");
+
+	// source -> sink, 200 frames through a 16-deep stream with a slow consumer
+	Runner r;
+	auto src = std::make_shared<Test_source>();
+	src->samples = uniform(200 * 64 * 2, 1);
+	src->frame_size = 64;
+	auto sink = std::make_shared<Test_sink>();
+	r.add_node(1, src);
+	r.add_node(2, sink);
+	r.add_link({1, "output", 2, "input"});
+	CHECK(r.run(), "runner ok");
+	CHECK(sink->frames.size() == 200, "all frames arrive: " << sink->frames.size());
+	CHECK(sink->interleaved() == src->samples, "payload intact and in order");
+	CHECK(sink->max_fill == 16, "producer ran into back-pressure (max fill " << sink->max_fill << ")");
+	CHECK(r.context_switches() > 400, "fibers interleave");
+	CHECK(sink->frames[3]->data()->pts == (int64_t)(3 * 64 / 48000.0 * 1000000), "pts");
+	for (auto& [id, res] : r.get_processor_resources()) CHECK(res->state == Runner::State::Finished, "state of node " << id);
+}
+
+static void test_registry_and_json()
+{
+	infra::Processor::processor_map.clear();
+	infra::register_all_processors();
+	const char* ids[] = {"audio_volume_adjust", "velocity_modifier", "pitch_modifier", "audio_amix", "audio_bimix", "audio_bimix_v2", "audio_spectrum"};
+	for (auto id : ids) CHECK(infra::Processor::processor_map.count(id) == 1, "registered " << id);
+	bool threw = false;
+	try { infra::register_all_processors(); } catch (const std::logic_error&) { threw = true; }
+	CHECK(threw, "duplicate registration throws logic_error (processor.hpp:122-126)");
+	auto amix = infra::Processor::processor_map["audio_amix"].generate();
+	CHECK(amix->get_pin_attributes().size() == 3, "amix default pins: output + input_1 + input_2");
+	Json::Value v;
+	v["input_num"] = 3;
+	for (int i = 0; i < 3; i++) { v[infra::fmt("volumes%d", i)] = 0.25 * (i + 1); v[infra::fmt("locks%d", i)] = (i == 1); }
+	amix->deserialize(v);
+	CHECK(amix->get_pin_attributes().size() == 4 && amix->get_pin_attributes()[3].identifier == "input_3", "pins follow input_num");
+	auto back = amix->serialize();
+	CHECK(back["input_num"].asInt() == 3 && back["volumes2"].asFloat() == 0.75f && back["locks1"].asBool(), "amix JSON round trip");
+	bool bad = false;
+	try { amix->deserialize(Json::Value()); } catch (const infra::Processor::Runtime_error& e) { bad = e.detail == "Wrong field: input_num"; }
+	CHECK(bad, "missing input_num -> Runtime_error");
+	auto bimix = infra::Processor::processor_map["audio_bimix"].generate();
+	Json::Value b;
+	b["bias"] = 7.0;
+	bimix->deserialize(b);
+	CHECK(bimix->serialize()["bias"].asFloat() == 1.0f, "bias clamps to [-1, 1] (audio-bimix.cpp:381-382)");
+	auto vel = infra::Processor::processor_map["velocity_modifier"].generate();
+	Json::Value q;
+	q["velocity"] = 1.5;
+	q["keep_pitch"] = true;
+	vel->deserialize(q);
+	CHECK(vel->serialize()["velocity"].asFloat() == 1.5f && vel->serialize()["keep_pitch"].asBool(), "velocity JSON");
+	CHECK(infra::Processor::processor_map["audio_volume_adjust"].generate()->serialize().isNull(), "volume is not serialised (audio-vol.hpp:57-58)");
+}
+
+static void test_error_capture()
+{
+	// a node without its input link ends in State::Error with the reference's message, and stops the graph
+	Runner r;
+	auto vol = std::make_shared<Audio_vol>();
+	auto sink = std::make_shared<Test_sink>();
+	r.add_node(1, vol);
+	r.add_node(2, sink);
+	r.add_link({1, "output", 2, "input"});
+	CHECK(!r.run(), "runner reports the error");
+	auto& res = r.get_processor_resources().at(1);
+	CHECK(res->state == Runner::State::Error, "state Error");
+	bool ok = false;
+	try { std::any_cast<infra::Processor::Runtime_error>(res->exception); ok = true; } catch (...) {}
+	CHECK(ok, "exception is a Processor::Runtime_error");
+	CHECK(res->error_text.find("Volume adjust processor has no input") == 0, res->error_text);
+}
+
+// ------------------------------------------------------------------------------------------------ GPU graphs
+static void test_gpu_volume()
+{
+	for (int format : {AV_SAMPLE_FMT_FLT, AV_SAMPLE_FMT_FLTP, AV_SAMPLE_FMT_S16})
+	{
+		Runner r;
+		auto src = std::make_shared<Test_source>();
+		src->samples = uniform(20000 * 2, 3);
+		src->format = format;
+		auto vol = std::make_shared<Audio_vol>();
+		vol->set_volume(0.5f);
+		auto sink = std::make_shared<Test_sink>();
+		r.add_node(1, src);
+		r.add_node(2, vol);
+		r.add_node(3, sink);
+		r.add_link({1, "output", 2, "input"});
+		r.add_link({2, "output", 3, "input"});
+		const bool ok = r.run();
+		CHECK(ok, "volume graph runs (format " << format << "): " << r.get_processor_resources().at(2)->error_text);
+		if (!ok) continue;
+		CHECK(sink->frames.size() == (20000 + 1151) / 1152, "frame count preserved");
+		size_t pos = 0;
+		bool same = true;
+		for (auto& f : sink->frames)
+		{
+			const Frame_data* d = f->data();
+			same = same && d->format == format && d->sample_rate == 48000 && d->pts == (int64_t)(double(pos) / 48000 * 1000000);
+			for (int i = 0; i < d->nb_samples && same; i++)
+				for (int c = 0; c < 2 && same; c++)
+				{
+					const float x = src->samples[(pos + i) * 2 + c];
+					if (format == AV_SAMPLE_FMT_FLT) same = reinterpret_cast<const float*>(d->data[0])[i * 2 + c] == x * 0.5f;
+					else if (format == AV_SAMPLE_FMT_FLTP) same = reinterpret_cast<const float*>(d->data[c])[i] == x * 0.5f;
+					else
+					{
+						const int16_t q = (int16_t)std::lrintf(x * 32767.0f);
+						same = reinterpret_cast<const int16_t*>(d->data[0])[i * 2 + c] == (int16_t)((float)q * 0.5f);
+					}
+				}
+			pos += d->nb_samples;
+		}
+		CHECK(same, "gain output bit-exact, metadata cloned (format " << format << ")");
+	}
+}
+
+static void test_gpu_amix()
+{
+	const int S = 1152 * 9 + 300;
+	Runner r;
+	auto a = std::make_shared<Test_source>(), b = std::make_shared<Test_source>();
+	a->samples = uniform(S * 2, 5);
+	b->samples = uniform(S * 2, 6);
+	b->format = AV_SAMPLE_FMT_FLTP;
+	auto mix = std::make_shared<Audio_amix>();
+	Json::Value v;
+	v["input_num"] = 2;
+	v["volumes0"] = 0.25; v["locks0"] = false;
+	v["volumes1"] = 0.75; v["locks1"] = false;
+	mix->deserialize(v);
+	auto sink = std::make_shared<Test_sink>();
+	r.add_node(1, a); r.add_node(2, b); r.add_node(3, mix); r.add_node(4, sink);
+	r.add_link({1, "output", 3, "input_1"});
+	r.add_link({2, "output", 3, "input_2"});
+	r.add_link({3, "output", 4, "input"});
+	const bool ok = r.run();
+	CHECK(ok, "amix graph runs: " << r.get_processor_resources().at(3)->error_text);
+	if (!ok) return;
+	std::vector<float> aL(S), aR(S), bL(S), bR(S), oL(S), oR(S);
+	for (int i = 0; i < S; i++) { aL[i] = a->samples[2 * i]; aR[i] = a->samples[2 * i + 1]; bL[i] = b->samples[2 * i]; bR[i] = b->samples[2 * i + 1]; }
+	const float* inL[2] = {aL.data(), bL.data()};
+	const float* inR[2] = {aR.data(), bR.data()};
+	const float vol[2] = {0.25f, 0.75f};
+	orc_amix_f32(inL, inR, vol, 2, oL.data(), oR.data(), S);
+	size_t pos = 0;
+	bool same = true;
+	double t = 0;
+	for (auto& f : sink->frames)
+	{
+		const Frame_data* d = f->data();
+		if (pos >= (size_t)S) { for (int i = 0; i < d->nb_samples; i++) same = same && reinterpret_cast<const float*>(d->data[0])[i] == 0.0f; continue; }  // flush frames are silence
+		same = same && d->format == AV_SAMPLE_FMT_FLTP && d->ch_layout.nb_channels == 2;
+		t += d->nb_samples / 48000.0;
+		same = same && d->pts == (int64_t)(t * 1000000);  // pts = END time (audio-amix.cpp:199-200)
+		const int n = (int)std::min<size_t>(d->nb_samples, S - pos);
+		same = same && std::memcmp(d->data[0], oL.data() + pos, n * sizeof(float)) == 0 && std::memcmp(d->data[1], oR.data() + pos, n * sizeof(float)) == 0;
+		pos += d->nb_samples;
+	}
+	CHECK(pos >= (size_t)S, "all samples mixed (" << pos << ")");
+	CHECK(same, "amix output bit-exact vs oracle, planar, pts = cumulative end time");
+}
+
+static void test_gpu_pitch_spectrum_fanout()
+{
+	const int S = 30000;
+	const float semis = 3.0f;
+	Runner r;
+	auto src = std::make_shared<Test_source>();
+	src->samples = uniform(S * 2, 7);
+	auto pitch = std::make_shared<Pitch_modifier>();
+	Json::Value v;
+	v["pitch"] = (double)semis;
+	pitch->deserialize(v);
+	auto spec = std::make_shared<Audio_spectrum>();
+	auto sink_audio = std::make_shared<Test_sink>(), sink_spec = std::make_shared<Test_sink>();
+	r.add_node(1, src); r.add_node(2, pitch); r.add_node(3, spec); r.add_node(4, sink_audio); r.add_node(5, sink_spec);
+	r.add_link({1, "output", 2, "input"});
+	r.add_link({2, "output", 3, "input"});   // fan-out: the pitch node pushes each frame to two streams
+	r.add_link({2, "output", 4, "input"});
+	r.add_link({3, "output", 5, "input"});
+	const bool ok = r.run();
+	CHECK(ok, "pitch->spectrum graph runs: " << r.get_processor_resources().at(2)->error_text << r.get_processor_resources().at(3)->error_text);
+	if (!ok) return;
+	const float p = std::pow(2.0f, semis / 12.0f);  // what Pitch_modifier passes (audio-velocity.cpp:474)
+	std::vector<float> ref(S * 2);
+	CHECK(orc_stretch_f32(src->samples.data(), S, 2, 1.0, (double)p, ref.data()) == 0, "oracle stretch");
+	const auto got = sink_audio->interleaved();
+	CHECK(got.size() == ref.size(), "pitch output length " << got.size());
+	CHECK(rel_rms(got, ref) <= 1e-4, "pitch output within 1e-4 RMS of the oracle: " << rel_rms(got, ref));
+	const size_t F = orc_spectrum_frames(S);
+	std::vector<float> sref(F * 2 * 513);
+	orc_spectrum_f32(got.data(), S, 2, sref.data());
+	CHECK(sink_spec->frames.size() == F, "spectrum frames " << sink_spec->frames.size() << " vs " << F);
+	bool same = sink_spec->frames.size() == F;
+	for (size_t f = 0; f < F && same; f++)
+	{
+		const Frame_data* d = sink_spec->frames[f]->data();
+		same = d->nb_samples == 513 && d->format == AV_SAMPLE_FMT_FLTP;
+		for (int c = 0; c < 2 && same; c++) same = std::memcmp(d->data[c], &sref[(f * 2 + c) * 513], 513 * sizeof(float)) == 0;
+	}
+	CHECK(same, "spectrum frames bit-exact vs oracle on the same input");
+	for (auto& f : sink_audio->frames) CHECK(f->data()->nb_samples <= 3456, "chunks no larger than 3*1152/velocity (audio-velocity.cpp:417)");
+}
+
+static void test_gpu_velocity_keep_pitch()
+{
+	const int S = 24000;
+	Runner r;
+	auto src = std::make_shared<Test_source>();
+	src->samples = uniform(S * 2, 9);
+	src->format = AV_SAMPLE_FMT_FLTP;
+	auto vel = std::make_shared<Velocity_modifier>();
+	Json::Value v;
+	v["velocity"] = 1.5;
+	v["keep_pitch"] = true;
+	vel->deserialize(v);
+	auto sink = std::make_shared<Test_sink>();
+	r.add_node(1, src); r.add_node(2, vel); r.add_node(3, sink);
+	r.add_link({1, "output", 2, "input"});
+	r.add_link({2, "output", 3, "input"});
+	CHECK(r.run(), "velocity graph runs: " << r.get_processor_resources().at(2)->error_text);
+	const float velocity = 1.5f;
+	std::vector<float> ref(16000 * 2);
+	CHECK(orc_stretch_f32(src->samples.data(), S, 2, (double)velocity, (double)(1 / velocity), ref.data()) == 0, "oracle");
+	const auto got = sink->interleaved();
+	CHECK(got.size() == ref.size(), "length S/velocity: " << got.size());
+	CHECK(rel_rms(got, ref) <= 1e-4, "velocity(keep pitch) within 1e-4 RMS: " << rel_rms(got, ref));
+}
+
+static void test_gpu_bimix_v2()
+{
+	const int S = 5000;
+	// left starts at t = 0, right 10 ms later: the first 480 output frames carry the left channel only
+	Runner r;
+	auto l = std::make_shared<Test_source>(), rr = std::make_shared<Test_source>();
+	l->samples = uniform(S * 2, 11);
+	rr->samples = uniform(S * 2, 12);
+	rr->start_seconds = 0.010;
+	auto mix = std::make_shared<Audio_bimix_v2>();
+	auto sink = std::make_shared<Test_sink>();
+	r.add_node(1, l); r.add_node(2, rr); r.add_node(3, mix); r.add_node(4, sink);
+	r.add_link({1, "output", 3, "input_l"});
+	r.add_link({2, "output", 3, "input_r"});
+	r.add_link({3, "output", 4, "input"});
+	const bool ok = r.run();
+	CHECK(ok, "bimix_v2 graph runs: " << r.get_processor_resources().at(3)->error_text);
+	if (!ok) return;
+	std::vector<float> lm(S), rm(S);
+	for (int i = 0; i < S; i++) { lm[i] = (float)((l->samples[2 * i] + l->samples[2 * i + 1]) * 0.5); rm[i] = (float)((rr->samples[2 * i] + rr->samples[2 * i + 1]) * 0.5); }
+	const auto got = sink->interleaved();
+	// walk the output: channel 0 must reproduce lm in order, channel 1 must reproduce rm in order after zeros
+	size_t il = 0, ir = 0;
+	bool same = true;
+	size_t lead = 0;
+	for (size_t i = 0; i < got.size() / 2; i++)
+	{
+		const float a = got[2 * i], b = got[2 * i + 1];
+		if (il < (size_t)S && a == lm[il]) il++; else same = same && a == 0.0f;
+		if (ir < (size_t)S && b == rm[ir]) ir++; else { same = same && b == 0.0f; if (ir == 0) lead++; }
+	}
+	CHECK(same, "every sample is either the next downmix sample of its side or silence");
+	CHECK(il == (size_t)S, "left side complete: " << il);
+	CHECK(ir + 2 >= (size_t)S, "right side complete up to the rounding slack the reference allows (audio-bimix.cpp:826): " << ir);
+	CHECK(lead >= 478 && lead <= 482, "right channel starts ~480 frames late: " << lead);
+}
+
+int main(int argc, char** argv)
+{
+	const std::string mode = argc > 1 ? argv[1] : "cpu";
+	test_streams_and_scheduler();
+	test_registry_and_json();
+	if (mode == "gpu")
+	{
+		test_error_capture();
+		test_gpu_volume();
+		test_gpu_amix();
+		test_gpu_pitch_spectrum_fanout();
+		test_gpu_velocity_keep_pitch();
+		test_gpu_bimix_v2();
+	}
+	std::cout << (failures ? "SELFTEST FAILED " : "SELFTEST OK ") << mode << " failures=" << failures << "\n";
+	return failures ? 1 : 0;
+}

@@ -1,0 +1,76 @@
+"""CPU, world_size 2, gloo: the N>1 path of bench.py — stream sharding, the one-shot broadcast of the shared source
+buffer, and the max-over-ranks timing — exercised without a GPU."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, per_rank, n, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import naeload
+    import orc
+    nae = naeload.load()
+    from nodey_audio_editor_amd import shard
+    dist = shard.init("gloo", rank, world)
+    first, last = shard.stream_range(rank, per_rank)
+    # every rank generates ITS streams; rank 0 also generates the shared second input and broadcasts it
+    mine = [orc.fill_uniform(n, shard.stream_seed(s, 0)) for s in range(first, last)]
+    shared = torch.zeros(n, dtype=torch.float32)
+    if rank == 0:
+        shared = torch.from_numpy(orc.fill_uniform(n, shard.stream_seed(0, 1)))
+    shard.broadcast_shared(dist, shared, 0)
+    elapsed = shard.max_over_ranks(dist, 0.010 * (rank + 1))
+    dist.barrier()
+    q.put((rank, first, last, [float(m[0]) for m in mine], shared.numpy().copy(), elapsed))
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_and_broadcast():
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+    world, per_rank, n = 2, 3, 4096
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, per_rank, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref_shared = orc.fill_uniform(n, (0x9E3779B97F4A7C15 * 1 + 1) & 0xFFFFFFFFFFFFFFFF)
+    covered = []
+    for rank, first, last, firsts, shared, elapsed in res:
+        assert (first, last) == (rank * per_rank, (rank + 1) * per_rank)
+        covered += list(range(first, last))
+        assert np.array_equal(shared, ref_shared)               # broadcast delivered rank 0's buffer
+        assert abs(elapsed - 0.020) < 1e-9                      # max over ranks
+        for i, s in enumerate(range(first, last)):
+            assert firsts[i] == float(orc.fill_uniform(1, (0x9E3779B97F4A7C15 * (1 + s)) & 0xFFFFFFFFFFFFFFFF)[0])
+    assert covered == list(range(world * per_rank))             # disjoint and complete
+
+
+def test_job_throughput_is_whole_job(nae):
+    from nodey_audio_editor_amd import shard
+    assert shard.job_throughput(8, 1024, 480000, 5, 0.25) == 8 * 1024 * 480000 * 5 / 0.25
+    assert shard.stream_seed(0, 1) == (0x9E3779B97F4A7C15 + 1) & 0xFFFFFFFFFFFFFFFF
+    assert shard.stream_range(3, 128) == (384, 512)
