@@ -14,6 +14,7 @@
 // see DESIGN.md §3) and the FFTW-based spectrum the reference declares but never implements (K8).
 #include "nae_internal.h"
 #include "stft_device.h"
+#include <stdlib.h>
 
 namespace nae {
 
@@ -97,6 +98,8 @@ struct PvParams {
     int ch;
     int tile;             // frames (== output hop blocks) per tile
     int n_tiles;
+    long long f_origin;   // first frame / output block of tile 0 (0 in block mode; > 0 when a stream is continued)
+    long long f_stop;     // one past the last frame / block this launch is responsible for
 };
 
 __device__ __forceinline__ long long frame_start(const PvParams& p, long long f)
@@ -154,9 +157,9 @@ __global__ __launch_bounds__(kThreads, 4) void pv_phase_kernel(SigViewD src, PvP
     load_fft_tw(tw, tb.w512, L.w64, lane);
     const int kl = kl_of_lane(lane);
 
-    const long long f0 = (long long)tile * p.tile;
+    const long long f0 = p.f_origin + (long long)tile * p.tile;
     long long f1 = f0 + p.tile;
-    if (f1 > p.frames) f1 = p.frames;
+    if (f1 > p.f_stop) f1 = p.f_stop;
 
     uint32_t acc[9], qp[9], qa[9];
 #pragma unroll
@@ -169,10 +172,12 @@ __global__ __launch_bounds__(kThreads, 4) void pv_phase_kernel(SigViewD src, PvP
         const long long s = frame_start(p, f);
         const cf nyq = analyse<kUnit>(v, in, s, L, tw, lane);
         phases_of(v, nyq, qa);
-        if (f == 0) {
+        if (f < f0) {
+            // priming frame: its increment belongs to the previous tile / call
+        } else if (f == 0) {
 #pragma unroll
             for (int r = 0; r < 9; r++) acc[r] = qa[r]; // the "increment" of frame 0 is its analysis phase
-        } else if (f >= f0) {
+        } else {
             const unsigned d = (unsigned)(s - s_prev);
             const unsigned R = (d == (unsigned)p.d0) ? p.r_q24_0 : p.r_q24_1;
             phase_inc(qa, qp, acc, kl, d, R);
@@ -187,20 +192,23 @@ __global__ __launch_bounds__(kThreads, 4) void pv_phase_kernel(SigViewD src, PvP
     if (lane == 0) o[512] = acc[8];
 }
 
-// pass 2: exclusive prefix over tiles, in place.  one thread per (stream-channel, bin)
-__global__ void pv_scan_kernel(uint32_t* __restrict__ sums, long long n_sc, int n_tiles)
+// pass 2: exclusive prefix over tiles, in place.  one thread per (stream-channel, bin).
+// carry_in (optional): phase in front of tile 0, [n_sc][520]; carry_out (optional): phase behind the last tile.
+__global__ void pv_scan_kernel(uint32_t* __restrict__ sums, long long n_sc, int n_tiles,
+                               const uint32_t* __restrict__ carry_in, uint32_t* __restrict__ carry_out)
 {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long sc = t / kT1024Pad;
     const int k = (int)(t % kT1024Pad);
     if (sc >= n_sc || k >= NAE_FFT_BINS) return;
     uint32_t* p = sums + sc * n_tiles * (long long)kT1024Pad + k;
-    uint32_t run = 0;
+    uint32_t run = carry_in ? carry_in[sc * kT1024Pad + k] : 0u;
     for (int j = 0; j < n_tiles; j++) {
         const uint32_t v = p[(long long)j * kT1024Pad];
         p[(long long)j * kT1024Pad] = run;
         run += v;
     }
+    if (carry_out) carry_out[sc * kT1024Pad + k] = run;
 }
 
 struct OutViewD { float* base; long long ss, cs, fs; };
@@ -226,10 +234,11 @@ __global__ __launch_bounds__(kThreads, 4) void pv_synth_kernel(SigViewD src, PvP
     load_fft_tw(tw, tb.w512, L.w64, lane);
     const int kl = kl_of_lane(lane);
 
-    const long long b0 = (long long)tile * p.tile;          // first output block == first frame of the tile
-    long long f_end = b0 + p.tile + 3;                      // frames b0 .. b0+T+2 feed blocks b0 .. b0+T-1
+    const long long b0 = p.f_origin + (long long)tile * p.tile; // first output block == first frame of the tile
+    long long b_end = b0 + p.tile;
+    if (b_end > p.f_stop) b_end = p.f_stop;
+    long long f_end = b_end + 3;                            // frames b0 .. b_end+2 feed blocks b0 .. b_end-1
     if (f_end > p.frames) f_end = p.frames;
-    const long long b_end = b0 + p.tile;
 
     uint32_t qs[9], qp[9];
     {
@@ -340,7 +349,7 @@ __global__ __launch_bounds__(kThreads, 4) void pv_synth_kernel(SigViewD src, PvP
 }
 
 // rate transposer: out[j] = sum_i tab(phase)[i] * v[idx - 7 + i],  pos = j * step (Q32.32)
-struct RsParams { unsigned long long step_q32; long long src_len; long long out_len; int ch; };
+struct RsParams { unsigned long long step_q32; long long src_len; long long out_len; int ch; long long j_begin; };
 
 __global__ __launch_bounds__(256) void resample_kernel(SigViewD src, RsParams p, long long n_streams,
                                                       const float* __restrict__ tab, OutViewD out)
@@ -348,7 +357,7 @@ __global__ __launch_bounds__(256) void resample_kernel(SigViewD src, RsParams p,
     __shared__ float stab[(NAE_RS_PHASES + 1) * NAE_RS_TAPS];
     for (int i = threadIdx.x; i < (NAE_RS_PHASES + 1) * NAE_RS_TAPS; i += blockDim.x) stab[i] = tab[i];
     __syncthreads();
-    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long j = p.j_begin + (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long s = blockIdx.y;
     if (j >= p.out_len) return;
     const unsigned long long lo = (unsigned long long)j * p.step_q32;
@@ -389,7 +398,7 @@ __global__ __launch_bounds__(256) void resample_tile_kernel(SigViewD src, RsPara
     float* stage = stab + (NAE_RS_PHASES + 1) * NAE_RS_TAPS;                   // [ch][span_alloc]
     for (int i = threadIdx.x; i < (NAE_RS_PHASES + 1) * NAE_RS_TAPS; i += 256) stab[i] = tab[i];
     const long long s = blockIdx.y;
-    const long long j0 = (long long)blockIdx.x * kRsOut;
+    const long long j0 = p.j_begin + (long long)blockIdx.x * kRsOut;
     long long j1 = j0 + kRsOut;
     if (j1 > p.out_len) j1 = p.out_len;
     // source window [m_lo, m_hi) of this tile, m_lo rounded down to a multiple of 4 samples
@@ -496,33 +505,36 @@ int nae_launch_spectrum(nae_ctx* ctx, const nae_sig* src, size_t T, int ch, size
     return nae_check(ctx, hipGetLastError(), "spectrum_kernel");
 }
 
-static PvParams make_pv_params(const nae_stretch_plan& pl, size_t in_len, int ch, int tile)
+static PvParams make_pv_params(const nae_stretch_plan& pl, size_t in_len, int ch, int tile, const nae_pv_segment* seg)
 {
     PvParams p;
     p.ha_q24 = pl.ha_q24;
     p.in_len = (long long)in_len;
-    p.frames = (long long)pl.frames;
-    p.mid_len = (long long)pl.mid_len;
+    p.frames = seg ? seg->f_limit : (long long)pl.frames;
+    p.mid_len = seg ? seg->mid_limit : (long long)pl.mid_len;
     p.d0 = pl.d0;
     p.r_q24_0 = pl.r_q24[0];
     p.r_q24_1 = pl.r_q24[1];
     p.ch = ch;
     p.tile = tile;
-    p.n_tiles = (int)((pl.frames + tile - 1) / tile);
+    p.f_origin = seg ? seg->f_origin : 0;
+    const long long cnt = seg ? seg->f_count : (long long)pl.frames;
+    p.f_stop = p.f_origin + cnt;
+    p.n_tiles = (int)((cnt + tile - 1) / tile);
     return p;
 }
 
-size_t nae_pv_phase_workspace_bytes(const nae_stretch_plan* pl, int ch, size_t n_streams, int tile)
+size_t nae_pv_phase_workspace_bytes(size_t n_frames, int ch, size_t n_streams, int tile)
 {
-    const size_t n_tiles = (pl->frames + tile - 1) / tile;
+    const size_t n_tiles = (n_frames + tile - 1) / tile;
     return n_streams * ch * n_tiles * kT1024Pad * sizeof(uint32_t);
 }
 
 // pass 1 + 2: leaves the exclusive tile-prefix phases in `phase_ws`
 int nae_launch_pv_phase(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig* src, size_t in_len, int ch,
-                        size_t n_streams, int tile, uint32_t* phase_ws)
+                        size_t n_streams, int tile, uint32_t* phase_ws, const nae_pv_segment* seg)
 {
-    PvParams p = make_pv_params(*pl, in_len, ch, tile);
+    PvParams p = make_pv_params(*pl, in_len, ch, tile, seg);
     const long long items = (long long)n_streams * ch * p.n_tiles;
     if (items == 0) return NAE_OK;
     Tables tb{ctx->d_w512, ctx->d_t1024, ctx->d_hann};
@@ -542,15 +554,17 @@ int nae_launch_pv_phase(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig*
         const long long n_sc = (long long)n_streams * ch;
         const long long threads = n_sc * kT1024Pad;
         const unsigned grid = (unsigned)((threads + 255) / 256);
-        NAE_KLAUNCH(ctx, "pv_scan_kernel", pv_scan_kernel, dim3(grid), dim3(256), 0, ctx->stream, phase_ws, n_sc, p.n_tiles);
+        NAE_KLAUNCH(ctx, "pv_scan_kernel", pv_scan_kernel, dim3(grid), dim3(256), 0, ctx->stream, phase_ws, n_sc, p.n_tiles,
+                    seg ? seg->carry_in : nullptr, seg ? seg->carry_out : nullptr);
         return nae_check(ctx, hipGetLastError(), "pv_scan_kernel");
     }
 }
 
 int nae_launch_pv_synth(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig* src, size_t in_len, int ch,
-                        size_t n_streams, int tile, const uint32_t* phase_ws, const nae_sig* out)
+                        size_t n_streams, int tile, const uint32_t* phase_ws, const nae_sig* out,
+                        const nae_pv_segment* seg)
 {
-    PvParams p = make_pv_params(*pl, in_len, ch, tile);
+    PvParams p = make_pv_params(*pl, in_len, ch, tile, seg);
     const long long items = (long long)n_streams * ch * p.n_tiles;
     if (items == 0) return NAE_OK;
     Tables tb{ctx->d_w512, ctx->d_t1024, ctx->d_hann};
@@ -565,18 +579,21 @@ int nae_launch_pv_synth(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig*
     return nae_check(ctx, hipGetLastError(), "pv_synth_kernel");
 }
 
+// outputs [j_begin, j_end) (whole plan when j_end == 0)
 int nae_launch_resample(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig* src, size_t src_len, int ch,
-                        size_t n_streams, const float* d_tab, const nae_sig* out)
+                        size_t n_streams, const float* d_tab, const nae_sig* out, size_t j_begin, size_t j_end)
 {
-    if (pl->out_len == 0 || n_streams == 0) return NAE_OK;
-    RsParams p{pl->step_q32, (long long)src_len, (long long)pl->out_len, ch};
+    if (j_end == 0) j_end = pl->out_len;
+    if (j_end <= j_begin || n_streams == 0) return NAE_OK;
+    RsParams p{pl->step_q32, (long long)src_len, (long long)j_end, ch, (long long)j_begin};
+    const size_t count = j_end - j_begin;
     // tiled kernel while one tile's source span fits the staging buffer (rho <= 4), else the direct kernel
     const double rho = (double)pl->step_q32 / 4294967296.0;
     const long long span_need = (long long)(kRsOut * rho) + NAE_RS_TAPS + 8;
-    const bool tiled = span_need <= kRsMaxSpan;
+    const bool tiled = span_need <= kRsMaxSpan && !getenv("NAE_RS_DIRECT");
     const int span_alloc = (int)((span_need + 3) & ~3ll);
     const size_t lds = ((NAE_RS_PHASES + 1) * NAE_RS_TAPS + (size_t)ch * span_alloc) * sizeof(float);
-    const unsigned gx = tiled ? (unsigned)((pl->out_len + kRsOut - 1) / kRsOut) : (unsigned)((pl->out_len + 255) / 256);
+    const unsigned gx = tiled ? (unsigned)((count + kRsOut - 1) / kRsOut) : (unsigned)((count + 255) / 256);
     // blockIdx.y is limited to 65535
     for (size_t s0 = 0; s0 < n_streams; s0 += 65535) {
         const size_t ns = (n_streams - s0 < 65535) ? n_streams - s0 : 65535;

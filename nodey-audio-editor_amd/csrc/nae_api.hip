@@ -120,7 +120,7 @@ static void build_rs_table(double rate_eff, std::vector<float>& tab)
     }
 }
 
-static int ensure_rs_table(nae_ctx* ctx, double rate_eff)
+int nae_ensure_rs_table(nae_ctx* ctx, double rate_eff)
 {
     if (ctx->d_rs_tab && ctx->rs_tab_rate == rate_eff) return NAE_OK;
     if (!ctx->d_rs_tab) {
@@ -373,7 +373,7 @@ int nae_stretch_block_f32(nae_ctx* ctx, double rate, double pitch, const nae_sig
     nae_sig mid{};
     if (pl.pv_on) {
         const int tile = ctx->pv_tile;
-        rc = nae_ws_reserve(ctx, &ctx->ws_phase, &ctx->ws_phase_bytes, nae_pv_phase_workspace_bytes(&pl, ch, n_streams, tile));
+        rc = nae_ws_reserve(ctx, &ctx->ws_phase, &ctx->ws_phase_bytes, nae_pv_phase_workspace_bytes(pl.frames, ch, n_streams, tile));
         if (rc) return rc;
         const nae_sig* pv_out = dst;
         if (pl.rs_on) {
@@ -385,15 +385,15 @@ int nae_stretch_block_f32(nae_ctx* ctx, double rate, double pitch, const nae_sig
             rs_src = &mid;
             rs_src_len = pl.mid_len;
         }
-        rc = nae_launch_pv_phase(ctx, &pl, src, in_len, ch, n_streams, tile, static_cast<uint32_t*>(ctx->ws_phase));
+        rc = nae_launch_pv_phase(ctx, &pl, src, in_len, ch, n_streams, tile, static_cast<uint32_t*>(ctx->ws_phase), nullptr);
         if (rc) return rc;
-        rc = nae_launch_pv_synth(ctx, &pl, src, in_len, ch, n_streams, tile, static_cast<const uint32_t*>(ctx->ws_phase), pv_out);
+        rc = nae_launch_pv_synth(ctx, &pl, src, in_len, ch, n_streams, tile, static_cast<const uint32_t*>(ctx->ws_phase), pv_out, nullptr);
         if (rc) return rc;
     }
     if (pl.rs_on) {
-        rc = ensure_rs_table(ctx, pl.rate_eff);
+        rc = nae_ensure_rs_table(ctx, pl.rate_eff);
         if (rc) return rc;
-        rc = nae_launch_resample(ctx, &pl, rs_src, rs_src_len, ch, n_streams, ctx->d_rs_tab, dst);
+        rc = nae_launch_resample(ctx, &pl, rs_src, rs_src_len, ch, n_streams, ctx->d_rs_tab, dst, 0, 0);
         if (rc) return rc;
     }
     return NAE_OK;
@@ -416,10 +416,10 @@ int nae_debug_pv_tile_phase(nae_ctx* ctx, double rate, double pitch, const nae_s
     *tile_frames = (size_t)tile;
     const size_t need = n_streams * ch * n_tiles * NAE_FFT_BINS;
     if (dst_capacity < need) return nae_fail(ctx, NAE_ERR_INVALID, "destination too small");
-    const size_t ws_bytes = nae_pv_phase_workspace_bytes(&pl, ch, n_streams, tile);
+    const size_t ws_bytes = nae_pv_phase_workspace_bytes(pl.frames, ch, n_streams, tile);
     rc = nae_ws_reserve(ctx, &ctx->ws_phase, &ctx->ws_phase_bytes, ws_bytes);
     if (rc) return rc;
-    rc = nae_launch_pv_phase(ctx, &pl, src, in_len, ch, n_streams, tile, static_cast<uint32_t*>(ctx->ws_phase));
+    rc = nae_launch_pv_phase(ctx, &pl, src, in_len, ch, n_streams, tile, static_cast<uint32_t*>(ctx->ws_phase), nullptr);
     if (rc) return rc;
     std::vector<int32_t> tmp(ws_bytes / sizeof(int32_t));
     hipError_t e = hipMemcpyAsync(tmp.data(), ctx->ws_phase, ws_bytes, hipMemcpyDeviceToHost, ctx->stream);

@@ -55,13 +55,23 @@ int nae_ws_reserve(nae_ctx* ctx, void** p, size_t* have, size_t want);
 // kernels_stft.hip
 int nae_launch_spectrum(nae_ctx* ctx, const nae_sig* src, size_t T, int ch, size_t n_streams, float* dst,
                         size_t dst_stream_stride);
-size_t nae_pv_phase_workspace_bytes(const nae_stretch_plan* pl, int ch, size_t n_streams, int tile);
+// a continued stream processes frames / hop blocks [f_origin, f_origin + f_count) per call
+struct nae_pv_segment {
+    long long f_origin, f_count;
+    long long f_limit;            // frames >= f_limit are not available yet (or do not exist)
+    long long mid_limit;          // stretched samples >= mid_limit are not stored
+    const uint32_t* carry_in;     // [n_streams*ch][520] phase behind frame f_origin-1 (null: zero)
+    uint32_t* carry_out;          // receives the phase behind frame f_origin+f_count-1 (null: not wanted)
+};
+size_t nae_pv_phase_workspace_bytes(size_t n_frames, int ch, size_t n_streams, int tile);
 int nae_launch_pv_phase(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig* src, size_t in_len, int ch,
-                        size_t n_streams, int tile, uint32_t* phase_ws);
+                        size_t n_streams, int tile, uint32_t* phase_ws, const nae_pv_segment* seg);
 int nae_launch_pv_synth(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig* src, size_t in_len, int ch,
-                        size_t n_streams, int tile, const uint32_t* phase_ws, const nae_sig* out);
+                        size_t n_streams, int tile, const uint32_t* phase_ws, const nae_sig* out,
+                        const nae_pv_segment* seg);
 int nae_launch_resample(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig* src, size_t src_len, int ch,
-                        size_t n_streams, const float* d_tab, const nae_sig* out);
+                        size_t n_streams, const float* d_tab, const nae_sig* out, size_t j_begin, size_t j_end);
+int nae_ensure_rs_table(nae_ctx* ctx, double rate_eff);
 constexpr int kPhasePad = 520; // int32 per (stream-channel, tile) record in the phase workspace
 
 // kernels_nodes.hip

@@ -4,7 +4,10 @@
 // audio-velocity.cpp:369-428): putSamples / numSamples / receiveSamples / flush.
 #include "nae_internal.h"
 #include <new>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+#include <utility>
 
 namespace {
 
@@ -42,13 +45,29 @@ void devbuf_free(DevBuf& b)
 
 } // namespace
 
+// A FIFO of device samples addressed by ABSOLUTE index: element i (i >= base) lives at cur.p[(i - base) * width + ...].
+// Dropping the consumed head copies the tail into the alternate buffer (regions may overlap, so never in place).
+struct DevFifo {
+    DevBuf cur, alt;
+    size_t base = 0;   // absolute index of cur.p[0]
+};
+
 struct nae_stretch {
     nae_ctx* ctx;
     int sample_rate, ch;
     double rate, pitch;
-    DevBuf in, out;
-    size_t out_read = 0; // sample-frames already handed out
-    size_t out_frames = 0;
+    nae_stretch_plan pl{};        // parameters (in_len = 0)
+    DevFifo in;                   // interleaved input, sample-frames [in.base, in_total)
+    size_t in_total = 0;
+    // phase vocoder
+    size_t blocks_done = 0;       // hop blocks produced == frames folded into the carried phase
+    uint32_t* carry[2] = {nullptr, nullptr};
+    int carry_cur = 0;
+    DevFifo mid;                  // planar stretched signal, per-channel capacity mid_cap, samples [mid.base, mid_total)
+    size_t mid_cap = 0, mid_total = 0;
+    // output
+    DevFifo out;                  // interleaved result, sample-frames [out.base, out_total)
+    size_t out_total = 0, out_read = 0;
     bool flushed = false;
 };
 
@@ -60,6 +79,197 @@ struct nae_spectrum {
     size_t out_read = 0; // frames handed out
     size_t out_frames = 0;
 };
+
+namespace {
+
+void fifo_free(DevFifo& f) { devbuf_free(f.cur); devbuf_free(f.alt); }
+
+// keep elements [new_base, total) of an interleaved FIFO (width floats per element)
+int fifo_drop_interleaved(nae_ctx* ctx, DevFifo& f, size_t new_base, size_t total, size_t width)
+{
+    if (new_base <= f.base) return NAE_OK;
+    const size_t keep = total > new_base ? (total - new_base) * width : 0;
+    f.alt.len = 0;
+    int rc = devbuf_reserve(ctx, f.alt, keep ? keep : 1);
+    if (rc) return rc;
+    if (keep) {
+        hipError_t e = hipMemcpyAsync(f.alt.p, f.cur.p + (new_base - f.base) * width, keep * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream);
+        if (e != hipSuccess) return nae_check(ctx, e, "hipMemcpyAsync(fifo)");
+    }
+    std::swap(f.cur, f.alt);
+    f.cur.len = keep;
+    f.base = new_base;
+    return NAE_OK;
+}
+
+// make room for elements up to `want_total` (absolute), interleaved; [f.base, used_total) is live and survives a grow
+int fifo_reserve_interleaved(nae_ctx* ctx, DevFifo& f, size_t used_total, size_t want_total, size_t width)
+{
+    f.cur.len = used_total > f.base ? (used_total - f.base) * width : 0;
+    return devbuf_reserve(ctx, f.cur, (want_total > f.base ? want_total - f.base : 1) * width);
+}
+
+inline long long frame_start_host(const nae_stretch_plan& pl, long long f)
+{
+    return (((f - 1) * pl.ha_q24 + (1ll << (NAE_HA_FRAC_BITS - 1))) >> NAE_HA_FRAC_BITS) - NAE_FFT_N / 2;
+}
+
+// number of leading frames whose 1024-sample window lies inside [.., in_total)
+size_t frames_available(const nae_stretch_plan& pl, size_t in_total)
+{
+    if (in_total < NAE_FFT_N / 2) return 0;
+    // estimate, then correct with the exact start formula
+    long long f = (long long)(((double)in_total - 512.0) / ((double)pl.ha_q24 / (double)(1 << NAE_HA_FRAC_BITS))) + 2;
+    if (f < 0) f = 0;
+    while (f > 0 && frame_start_host(pl, f - 1) + NAE_FFT_N > (long long)in_total) f--;
+    while (frame_start_host(pl, f) + NAE_FFT_N <= (long long)in_total) f++;
+    return (size_t)f;
+}
+
+int stretch_process(nae_stretch* h)
+{
+    nae_ctx* ctx = h->ctx;
+    const int ch = h->ch;
+    const nae_stretch_plan& pl = h->pl;
+    nae_stretch_plan fin{};
+    if (h->flushed) {
+        int rc = nae_stretch_plan_make(h->rate, h->pitch, h->in_total, &fin);
+        if (rc) return rc;
+    }
+    // ---- neither stage: the node is a wire
+    if (!pl.pv_on && !pl.rs_on) {
+        const size_t n = h->in_total - h->out_total;
+        if (n) {
+            int rc = fifo_reserve_interleaved(ctx, h->out, h->out_total, h->in_total, ch);
+            if (rc) return rc;
+            hipError_t e = hipMemcpyAsync(h->out.cur.p + (h->out_total - h->out.base) * ch, h->in.cur.p + (h->out_total - h->in.base) * ch,
+                                          n * ch * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream);
+            if (e != hipSuccess) return nae_check(ctx, e, "hipMemcpyAsync(wire)");
+            h->out_total = h->in_total;
+            return fifo_drop_interleaved(ctx, h->in, h->in_total, h->in_total, ch);
+        }
+        return NAE_OK;
+    }
+    // ---- stage 1: phase vocoder over the hop blocks that became computable
+    if (pl.pv_on) {
+        size_t F_r, B_r;
+        long long mid_limit;
+        if (h->flushed) {
+            F_r = fin.frames;
+            B_r = (fin.mid_len + NAE_HOP - 1) / NAE_HOP;
+            mid_limit = (long long)fin.mid_len;
+        } else {
+            F_r = frames_available(pl, h->in_total);
+            B_r = F_r >= 3 ? F_r - 3 : 0;
+            mid_limit = (long long)1 << 60;
+        }
+        if (B_r > h->blocks_done) {
+            const int tile = ctx->pv_tile;
+            const size_t count = B_r - h->blocks_done;
+            int rc = nae_ws_reserve(ctx, &ctx->ws_phase, &ctx->ws_phase_bytes, nae_pv_phase_workspace_bytes(count, ch, 1, tile));
+            if (rc) return rc;
+            for (int i = 0; i < 2; i++)
+                if (!h->carry[i] && hipMalloc((void**)&h->carry[i], (size_t)ch * kPhasePad * sizeof(uint32_t)) != hipSuccess)
+                    return nae_fail(ctx, NAE_ERR_NOMEM, "hipMalloc(carry)");
+            nae_pv_segment seg{(long long)h->blocks_done, (long long)count, (long long)F_r, mid_limit,
+                               h->blocks_done ? h->carry[h->carry_cur] : nullptr, h->carry[h->carry_cur ^ 1]};
+            nae_sig src{h->in.cur.p - (ptrdiff_t)h->in.base * ch, 0, 1, (size_t)ch};   // absolute indexing
+            nae_sig dst;
+            size_t produced_total = h->flushed ? fin.mid_len : B_r * NAE_HOP;
+            if (pl.rs_on) {
+                // planar mid FIFO: grow (re-pack planes) when the per-channel capacity is too small
+                const size_t need = produced_total - h->mid.base;
+                if (need > h->mid_cap) {
+                    size_t cap = h->mid_cap ? h->mid_cap : 1 << 15;
+                    while (cap < need) cap *= 2;
+                    h->mid.alt.len = 0;
+                    rc = devbuf_reserve(ctx, h->mid.alt, cap * ch);
+                    if (rc) return rc;
+                    const size_t keep = h->mid_total - h->mid.base;
+                    for (int c = 0; c < ch && keep; c++) {
+                        hipError_t e = hipMemcpyAsync(h->mid.alt.p + (size_t)c * cap, h->mid.cur.p + (size_t)c * h->mid_cap, keep * sizeof(float),
+                                                      hipMemcpyDeviceToDevice, ctx->stream);
+                        if (e != hipSuccess) return nae_check(ctx, e, "hipMemcpyAsync(mid grow)");
+                    }
+                    std::swap(h->mid.cur, h->mid.alt);
+                    h->mid_cap = cap;
+                }
+                dst = nae_sig{h->mid.cur.p - (ptrdiff_t)h->mid.base, 0, h->mid_cap, 1};
+            } else {
+                if (h->flushed && produced_total > fin.out_len) produced_total = fin.out_len;
+                rc = fifo_reserve_interleaved(ctx, h->out, h->out_total, produced_total, ch);
+                if (rc) return rc;
+                dst = nae_sig{h->out.cur.p - (ptrdiff_t)h->out.base * ch, 0, 1, (size_t)ch};
+                if (h->flushed) seg.mid_limit = (long long)fin.out_len;
+            }
+            if (getenv("NAE_TRACE")) fprintf(stderr, "[pv] blocks %zu -> %zu  F_r %zu in_total %zu in.base %zu produced_total %zu mid.base %zu cap %zu\n", h->blocks_done, B_r, F_r, h->in_total, h->in.base, produced_total, h->mid.base, h->mid_cap);
+            rc = nae_launch_pv_phase(ctx, &pl, &src, h->in_total, ch, 1, tile, static_cast<uint32_t*>(ctx->ws_phase), &seg);
+            if (rc) return rc;
+            rc = nae_launch_pv_synth(ctx, &pl, &src, h->in_total, ch, 1, tile, static_cast<const uint32_t*>(ctx->ws_phase), &dst, &seg);
+            if (rc) return rc;
+            h->carry_cur ^= 1;
+            h->blocks_done = B_r;
+            if (pl.rs_on) h->mid_total = produced_total;
+            else h->out_total = produced_total;
+            // input still needed: from the start of frame B_r - 1 (it primes the next call's phase difference)
+            const long long s_keep = frame_start_host(pl, (long long)B_r - 1);
+            rc = fifo_drop_interleaved(ctx, h->in, s_keep > 0 ? (size_t)s_keep : 0, h->in_total, ch);
+            if (rc) return rc;
+        }
+    }
+    // ---- stage 2: rate transposer over the outputs whose 16 taps are known
+    if (pl.rs_on) {
+        const size_t src_avail = pl.pv_on ? h->mid_total : h->in_total;
+        size_t J_r;
+        if (h->flushed) J_r = fin.out_len;
+        else if (src_avail <= NAE_RS_TAPS / 2) J_r = 0;
+        else {
+            const unsigned __int128 lim = ((unsigned __int128)(src_avail - NAE_RS_TAPS / 2) << 32) - 1;
+            J_r = (size_t)(lim / pl.step_q32) + 1;
+        }
+        if (J_r > h->out_total) {
+            int rc = nae_ensure_rs_table(ctx, pl.rate_eff);
+            if (rc) return rc;
+            rc = fifo_reserve_interleaved(ctx, h->out, h->out_total, J_r, ch);
+            if (rc) return rc;
+            nae_sig src = pl.pv_on ? nae_sig{h->mid.cur.p - (ptrdiff_t)h->mid.base, 0, h->mid_cap, 1}
+                                   : nae_sig{h->in.cur.p - (ptrdiff_t)h->in.base * ch, 0, 1, (size_t)ch};
+            nae_sig dst{h->out.cur.p - (ptrdiff_t)h->out.base * ch, 0, 1, (size_t)ch};
+            const size_t src_len = h->flushed ? (pl.pv_on ? fin.mid_len : h->in_total) : src_avail;
+            if (getenv("NAE_TRACE")) fprintf(stderr, "[rs] out_total %zu -> %zu  src_avail %zu src_len %zu mid.base %zu in.base %zu\n", h->out_total, J_r, src_avail, src_len, h->mid.base, h->in.base);
+            rc = nae_launch_resample(ctx, &pl, &src, src_len, ch, 1, ctx->d_rs_tab, &dst, h->out_total, J_r);
+            if (rc) return rc;
+            h->out_total = J_r;
+            // source still needed: from idx(J_r) - 7
+            const unsigned __int128 pos = (unsigned __int128)J_r * pl.step_q32;
+            // the tiled kernel stages from (idx - 7) rounded DOWN to a multiple of 4 samples: keep that much
+            const long long need_from = ((long long)(pos >> 32) - (NAE_RS_TAPS / 2 - 1)) & ~3ll;
+            const size_t nb = need_from > 0 ? (size_t)need_from : 0;
+            if (pl.pv_on) {
+                if (nb > h->mid.base) {   // planar: shift every plane
+                    const size_t nbase = nb < h->mid_total ? nb : h->mid_total;
+                    const size_t keep = h->mid_total - nbase;
+                    h->mid.alt.len = 0;
+                    rc = devbuf_reserve(ctx, h->mid.alt, h->mid_cap * ch);
+                    if (rc) return rc;
+                    for (int c = 0; c < ch && keep; c++) {
+                        hipError_t e = hipMemcpyAsync(h->mid.alt.p + (size_t)c * h->mid_cap, h->mid.cur.p + (size_t)c * h->mid_cap + (nbase - h->mid.base),
+                                                      keep * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream);
+                        if (e != hipSuccess) return nae_check(ctx, e, "hipMemcpyAsync(mid shift)");
+                    }
+                    std::swap(h->mid.cur, h->mid.alt);
+                    h->mid.base = nbase;
+                }
+            } else {
+                rc = fifo_drop_interleaved(ctx, h->in, nb < h->in_total ? nb : h->in_total, h->in_total, ch);
+                if (rc) return rc;
+            }
+        }
+    }
+    return NAE_OK;
+}
+
+} // namespace
 
 extern "C" {
 
@@ -81,6 +291,7 @@ int nae_stretch_create(nae_ctx* ctx, int sample_rate, int channels, float rate, 
     s->ch = channels;
     s->rate = rate;
     s->pitch = pitch;
+    s->pl = pl;
     *h = s;
     return NAE_OK;
 }
@@ -91,48 +302,40 @@ static int stretch_append(nae_stretch* h, const float* p, size_t S, bool host)
     if (h->flushed) return nae_fail(h->ctx, NAE_ERR_STATE, "put after flush");
     if (S == 0) return NAE_OK;
     const size_t n = S * h->ch;
-    int rc = devbuf_reserve(h->ctx, h->in, h->in.len + n);
+    int rc = fifo_reserve_interleaved(h->ctx, h->in, h->in_total, h->in_total + S, h->ch);
     if (rc) return rc;
-    hipError_t e = hipMemcpyAsync(h->in.p + h->in.len, p, n * sizeof(float), host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, h->ctx->stream);
+    hipError_t e = hipMemcpyAsync(h->in.cur.p + (h->in_total - h->in.base) * h->ch, p, n * sizeof(float),
+                                  host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, h->ctx->stream);
     if (e != hipSuccess) return nae_check(h->ctx, e, "hipMemcpyAsync(put)");
     if (host) (void)hipStreamSynchronize(h->ctx->stream); // the caller may reuse its buffer
-    h->in.len += n;
-    return NAE_OK;
+    h->in_total += S;
+    h->in.cur.len = (h->in_total - h->in.base) * h->ch;
+    return stretch_process(h);
 }
 
 int nae_stretch_put(nae_stretch* h, const float* interleaved, size_t S) { return stretch_append(h, interleaved, S, false); }
 int nae_stretch_put_host(nae_stretch* h, const float* interleaved, size_t S) { return stretch_append(h, interleaved, S, true); }
 
-// v1: the whole stream is transformed when flush() arrives (identical samples to the block call; the
-// incremental form that bounds memory is DESIGN.md §6 "next").
+// everything still buffered is transformed as if the input ended here (zero padding behind the last sample);
+// the samples delivered over the handle's life equal nae_stretch_block_f32 on the whole input, bit for bit
 int nae_stretch_flush(nae_stretch* h)
 {
     if (!h) return NAE_ERR_INVALID;
     if (h->flushed) return NAE_OK;
     h->flushed = true;
-    const size_t L = h->in.len / h->ch;
-    nae_stretch_plan pl;
-    int rc = nae_stretch_plan_make(h->rate, h->pitch, L, &pl);
-    if (rc) return rc;
-    h->out_frames = pl.out_len;
-    if (pl.out_len == 0) return NAE_OK;
-    rc = devbuf_reserve(h->ctx, h->out, pl.out_len * h->ch);
-    if (rc) return rc;
-    h->out.len = pl.out_len * h->ch;
-    nae_sig src{h->in.p, 0, 1, (size_t)h->ch}, dst{h->out.p, 0, 1, (size_t)h->ch};
-    return nae_stretch_block_f32(h->ctx, h->rate, h->pitch, &src, L, h->ch, 1, &dst);
+    return stretch_process(h);
 }
 
-size_t nae_stretch_available(nae_stretch* h) { return h ? h->out_frames - h->out_read : 0; }
+size_t nae_stretch_available(nae_stretch* h) { return h ? h->out_total - h->out_read : 0; }
 
 static int stretch_take(nae_stretch* h, float* dst, size_t max_frames, size_t* got, bool host)
 {
     if (!h || !got || (max_frames && !dst)) return NAE_ERR_INVALID;
-    size_t n = h->out_frames - h->out_read;
+    size_t n = h->out_total - h->out_read;
     if (n > max_frames) n = max_frames;
     *got = n;
     if (n == 0) return NAE_OK;
-    hipError_t e = hipMemcpyAsync(dst, h->out.p + h->out_read * h->ch, n * h->ch * sizeof(float),
+    hipError_t e = hipMemcpyAsync(dst, h->out.cur.p + (h->out_read - h->out.base) * h->ch, n * h->ch * sizeof(float),
                                   host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, h->ctx->stream);
     if (e != hipSuccess) return nae_check(h->ctx, e, "hipMemcpyAsync(receive)");
     if (host) {
@@ -140,6 +343,8 @@ static int stretch_take(nae_stretch* h, float* dst, size_t max_frames, size_t* g
         if (e != hipSuccess) return nae_check(h->ctx, e, "hipStreamSynchronize");
     }
     h->out_read += n;
+    // drop what has been handed out once it dominates the buffer
+    if (h->out_read - h->out.base > (1u << 16)) return fifo_drop_interleaved(h->ctx, h->out, h->out_read, h->out_total, h->ch);
     return NAE_OK;
 }
 
@@ -150,8 +355,11 @@ int nae_stretch_destroy(nae_stretch* h)
 {
     if (!h) return NAE_OK;
     (void)hipStreamSynchronize(h->ctx->stream);
-    devbuf_free(h->in);
-    devbuf_free(h->out);
+    fifo_free(h->in);
+    fifo_free(h->mid);
+    fifo_free(h->out);
+    for (int i = 0; i < 2; i++)
+        if (h->carry[i]) (void)hipFree(h->carry[i]);
     delete h;
     return NAE_OK;
 }

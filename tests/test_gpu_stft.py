@@ -226,33 +226,73 @@ def test_graph4_matches_node_by_node_oracle(ctx, nae):
         d.free()
 
 
+def stream_stretch(ctx, x, ch, rate, pitch, put_sizes, recv_chunk=3456, device_put=False):
+    """drive the SoundTouch-shaped handle the way audio-velocity.cpp:344-440 does: put a frame, drain what is ready"""
+    import ctypes as C
+    lib = ctx.lib
+    L = x.size // ch
+    h = C.c_void_p()
+    assert lib.nae_stretch_create(ctx.h, 48000, ch, rate, pitch, C.byref(h)) == 0
+    outs, avail_before_flush, pos, i = [], 0, 0, 0
+    d_x = ctx.array(x) if device_put else None
+
+    def drain(limit):
+        nonlocal outs
+        while lib.nae_stretch_available(h) > limit:
+            buf = np.empty(recv_chunk * ch, np.float32)
+            got = C.c_size_t()
+            assert lib.nae_stretch_receive_host(h, buf.ctypes.data, recv_chunk, C.byref(got)) == 0
+            outs.append(buf[: got.value * ch])
+
+    while pos < L:
+        n = min(put_sizes[i % len(put_sizes)], L - pos)
+        i += 1
+        if device_put:
+            assert lib.nae_stretch_put(h, d_x.at(pos * ch), n) == 0
+        else:
+            chunk = np.ascontiguousarray(x[pos * ch:(pos + n) * ch])
+            assert lib.nae_stretch_put_host(h, chunk.ctypes.data, n) == 0
+        pos += n
+        avail_before_flush = max(avail_before_flush, lib.nae_stretch_available(h))
+        drain(int(1152 / rate))
+    assert lib.nae_stretch_flush(h) == 0
+    drain(0)
+    assert lib.nae_stretch_destroy(h) == 0
+    if d_x is not None:
+        d_x.free()
+    return np.concatenate(outs) if outs else np.zeros(0, np.float32), avail_before_flush
+
+
+@pytest.mark.parametrize("rate,pitch", [(1.0, 2 ** (3 / 12)), (1.0, 2 ** (-4 / 12)), (1.5, 1 / 1.5), (0.7, 1 / 0.7), (1.5, 1.0),
+                                        (0.8, 1.0), (1.0, 1.0)])
+def test_stretch_streaming_equals_block(ctx, nae, rate, pitch):
+    """incremental put/receive yields exactly the block result, and output becomes available BEFORE flush"""
+    L, ch = 60000, 2
+    x = orc.fill_uniform(L * ch, 61)
+    rate, pitch = float(np.float32(rate)), float(np.float32(pitch))   # the handle takes floats (setRate/setPitch)
+    blk, pl = gpu_stretch(ctx, nae, x, ch, rate, pitch)
+    for sizes, dev in (([1152], False), ([1152, 4096, 37, 9000, 1, 20000], True), ([L], False)):
+        y, early = stream_stretch(ctx, x, ch, rate, pitch, sizes, device_put=dev)
+        assert y.size == blk.size, (sizes, y.size, blk.size)
+        assert np.array_equal(y, blk), (sizes, int(np.count_nonzero(y != blk)))
+        if len(sizes) == 1 and sizes[0] == 1152:
+            assert early > 0      # numSamples() grows while the stream is still being fed
+
+
 def test_streaming_handles(ctx, nae):
     import ctypes as C
     lib = ctx.lib
     L, ch = 20000, 2
     x = orc.fill_uniform(L * ch, 61)
     p = float(np.float32(2 ** (3 / 12)))   # the SoundTouch-shaped API takes float parameters (setPitch(float))
-    # --- stretch: put in uneven chunks (host), flush, drain in the reference's chunk sizes
     h = C.c_void_p()
-    assert lib.nae_stretch_create(ctx.h, 48000, ch, 1.0, p, C.byref(h)) == 0
-    pos = 0
-    for n in (1152, 4096, 37, 9000, L):
-        n = min(n, L - pos)
-        chunk = np.ascontiguousarray(x[pos * ch:(pos + n) * ch])
-        assert lib.nae_stretch_put_host(h, chunk.ctypes.data, n) == 0
-        pos += n
-    assert lib.nae_stretch_flush(h) == 0
-    outs = []
-    while lib.nae_stretch_available(h):
-        buf = np.empty(3456 * ch, np.float32)
-        got = C.c_size_t()
-        assert lib.nae_stretch_receive_host(h, buf.ctypes.data, 3456, C.byref(got)) == 0
-        outs.append(buf[: got.value * ch])
-    assert lib.nae_stretch_destroy(h) == 0
-    y = np.concatenate(outs)
-    blk, _ = gpu_stretch(ctx, nae, x, ch, 1.0, p)
-    assert np.array_equal(y, blk)
     assert lib.nae_stretch_create(ctx.h, 96000, ch, 1.0, p, C.byref(h)) == -2     # audio-velocity.cpp:371-379
+    assert lib.nae_stretch_create(ctx.h, 48000, 3, 1.0, p, C.byref(h)) == -1
+    # mono stream
+    xm = np.ascontiguousarray(x[0::2])
+    ym, _ = stream_stretch(ctx, xm, 1, 1.0, p, [1000])
+    bm, _ = gpu_stretch(ctx, nae, xm, 1, 1.0, p)
+    assert np.array_equal(ym, bm)
     # --- spectrum: chunked puts give the same frames as the block call
     hs = C.c_void_p()
     assert lib.nae_spectrum_create(ctx.h, 1024, 256, ch, C.byref(hs)) == 0
