@@ -100,6 +100,7 @@ struct PvParams {
     int n_tiles;
     long long f_origin;   // first frame / output block of tile 0 (0 in block mode; > 0 when a stream is continued)
     long long f_stop;     // one past the last frame / block this launch is responsible for
+    int skip_last;        // pass 1 only: the last tile's sum is not needed (nothing is carried on behind it)
 };
 
 __device__ __forceinline__ long long frame_start(const PvParams& p, long long f)
@@ -150,6 +151,7 @@ __global__ __launch_bounds__(kThreads, 4) void pv_phase_kernel(SigViewD src, PvP
     if (item >= n_items) return;
     const long long sc = item / p.n_tiles;
     const int tile = (int)(item % p.n_tiles);
+    if (p.skip_last && tile == p.n_tiles - 1) return;   // wave-uniform
     const long long s_idx = sc / p.ch;
     const int c = (int)(sc % p.ch);
     ChanView in{src.base + s_idx * src.ss + c * src.cs, src.fs, p.in_len};
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(kThreads, 4) void pv_phase_kernel(SigViewD src, PvP
 // pass 2: exclusive prefix over tiles, in place.  one thread per (stream-channel, bin).
 // carry_in (optional): phase in front of tile 0, [n_sc][520]; carry_out (optional): phase behind the last tile.
 __global__ void pv_scan_kernel(uint32_t* __restrict__ sums, long long n_sc, int n_tiles,
-                               const uint32_t* __restrict__ carry_in, uint32_t* __restrict__ carry_out)
+                               const uint32_t* __restrict__ carry_in, uint32_t* __restrict__ carry_out, int last_unwritten)
 {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long sc = t / kT1024Pad;
@@ -204,7 +206,7 @@ __global__ void pv_scan_kernel(uint32_t* __restrict__ sums, long long n_sc, int 
     uint32_t* p = sums + sc * n_tiles * (long long)kT1024Pad + k;
     uint32_t run = carry_in ? carry_in[sc * kT1024Pad + k] : 0u;
     for (int j = 0; j < n_tiles; j++) {
-        const uint32_t v = p[(long long)j * kT1024Pad];
+        const uint32_t v = (last_unwritten && j == n_tiles - 1) ? 0u : p[(long long)j * kT1024Pad];
         p[(long long)j * kT1024Pad] = run;
         run += v;
     }
@@ -214,8 +216,8 @@ __global__ void pv_scan_kernel(uint32_t* __restrict__ sums, long long n_sc, int 
 struct OutViewD { float* base; long long ss, cs, fs; };
 
 // pass 3: synthesis of one tile of output hop blocks [tile*T, (tile+1)*T)
-template <bool kUnit>
-__global__ __launch_bounds__(kThreads, 4) void pv_synth_kernel(SigViewD src, PvParams p, long long n_items,
+template <bool kUnit, int kOcc>
+__global__ __launch_bounds__(kThreads, kOcc) void pv_synth_kernel(SigViewD src, PvParams p, long long n_items,
                                                               const uint32_t* __restrict__ base_phase, OutViewD out,
                                                               Tables tb)
 {
@@ -521,6 +523,7 @@ static PvParams make_pv_params(const nae_stretch_plan& pl, size_t in_len, int ch
     const long long cnt = seg ? seg->f_count : (long long)pl.frames;
     p.f_stop = p.f_origin + cnt;
     p.n_tiles = (int)((cnt + tile - 1) / tile);
+    p.skip_last = 0;
     return p;
 }
 
@@ -530,32 +533,45 @@ size_t nae_pv_phase_workspace_bytes(size_t n_frames, int ch, size_t n_streams, i
     return n_streams * ch * n_tiles * kT1024Pad * sizeof(uint32_t);
 }
 
-// pass 1 + 2: leaves the exclusive tile-prefix phases in `phase_ws`
+// pass 1 + 2: leaves the exclusive tile-prefix phases in `phase_ws`.
+// The sum of the LAST tile is only needed when the phase behind it is carried on (a continued stream), so a block
+// call analyses n_tiles-1 tiles here, and nothing at all when the stream-channel is a single tile.
 int nae_launch_pv_phase(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig* src, size_t in_len, int ch,
                         size_t n_streams, int tile, uint32_t* phase_ws, const nae_pv_segment* seg)
 {
     PvParams p = make_pv_params(*pl, in_len, ch, tile, seg);
-    const long long items = (long long)n_streams * ch * p.n_tiles;
-    if (items == 0) return NAE_OK;
+    const long long n_sc = (long long)n_streams * ch;
+    if (n_sc * p.n_tiles == 0) return NAE_OK;
+    const bool need_last = seg && seg->carry_out;
     Tables tb{ctx->d_w512, ctx->d_t1024, ctx->d_hann};
+    if (p.n_tiles == 1 && !need_last) {
+        // base phase of the only tile: the carried phase, or zero
+        hipError_t e = (seg && seg->carry_in)
+            ? hipMemcpyAsync(phase_ws, seg->carry_in, (size_t)n_sc * kT1024Pad * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream)
+            : hipMemsetAsync(phase_ws, 0, (size_t)n_sc * kT1024Pad * sizeof(uint32_t), ctx->stream);
+        return nae_check(ctx, e, "phase base init");
+    }
     {
+        // items are (stream-channel, tile) with tile fastest; the kernel skips tile n_tiles-1 when it is not needed
+        PvParams pp = p;
+        pp.skip_last = need_last ? 0 : 1;
+        const long long items = n_sc * p.n_tiles;
         const unsigned grid = (unsigned)((items + kWaves - 1) / kWaves);
         const size_t lds = kLdsTables + kWaves * kLdsPerWaveSpec;
         if (src->frame_stride == 1)
             NAE_KLAUNCH(ctx, "pv_phase_kernel", (pv_phase_kernel<true>), dim3(grid), dim3(kThreads), lds, ctx->stream,
-                        to_view(src), p, items, phase_ws, tb);
+                        to_view(src), pp, items, phase_ws, tb);
         else
             NAE_KLAUNCH(ctx, "pv_phase_kernel", (pv_phase_kernel<false>), dim3(grid), dim3(kThreads), lds, ctx->stream,
-                        to_view(src), p, items, phase_ws, tb);
+                        to_view(src), pp, items, phase_ws, tb);
         int rc = nae_check(ctx, hipGetLastError(), "pv_phase_kernel");
         if (rc) return rc;
     }
     {
-        const long long n_sc = (long long)n_streams * ch;
         const long long threads = n_sc * kT1024Pad;
         const unsigned grid = (unsigned)((threads + 255) / 256);
         NAE_KLAUNCH(ctx, "pv_scan_kernel", pv_scan_kernel, dim3(grid), dim3(256), 0, ctx->stream, phase_ws, n_sc, p.n_tiles,
-                    seg ? seg->carry_in : nullptr, seg ? seg->carry_out : nullptr);
+                    seg ? seg->carry_in : nullptr, seg ? seg->carry_out : nullptr, need_last ? 0 : 1);
         return nae_check(ctx, hipGetLastError(), "pv_scan_kernel");
     }
 }
@@ -570,12 +586,13 @@ int nae_launch_pv_synth(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig*
     Tables tb{ctx->d_w512, ctx->d_t1024, ctx->d_hann};
     const unsigned grid = (unsigned)((items + kWaves - 1) / kWaves);
     const size_t lds = kLdsTables + kWaves * kLdsPerWavePv;
-    if (src->frame_stride == 1)
-        NAE_KLAUNCH(ctx, "pv_synth_kernel", (pv_synth_kernel<true>), dim3(grid), dim3(kThreads), lds, ctx->stream, to_view(src),
-                    p, items, phase_ws, to_out(out), tb);
-    else
-        NAE_KLAUNCH(ctx, "pv_synth_kernel", (pv_synth_kernel<false>), dim3(grid), dim3(kThreads), lds, ctx->stream, to_view(src),
-                    p, items, phase_ws, to_out(out), tb);
+    // few long tiles (<= one 512-thread workgroup per CU): the 2-waves-per-SIMD build has 256 VGPRs and no spills
+    const bool low_occ = grid <= 256 || getenv("NAE_PV_LOWOCC");
+#define NAE_SYNTH(U, O) NAE_KLAUNCH(ctx, "pv_synth_kernel", (pv_synth_kernel<U, O>), dim3(grid), dim3(kThreads), lds, ctx->stream, \
+                                    to_view(src), p, items, phase_ws, to_out(out), tb)
+    if (src->frame_stride == 1) { if (low_occ) NAE_SYNTH(true, 2); else NAE_SYNTH(true, 4); }
+    else { if (low_occ) NAE_SYNTH(false, 2); else NAE_SYNTH(false, 4); }
+#undef NAE_SYNTH
     return nae_check(ctx, hipGetLastError(), "pv_synth_kernel");
 }
 

@@ -24,7 +24,7 @@ struct nae_ctx {
     void* ws_mid = nullptr;   size_t ws_mid_bytes = 0;
     float* d_rs_tab = nullptr; double rs_tab_rate = 0.0;
     std::vector<float> h_rs_tab;
-    int pv_tile = 64;            // frames per phase-vocoder tile
+    int pv_tile = 0;             // frames per phase-vocoder tile; 0 = choose per call (nae_pick_pv_tile)
     // optional per-kernel timing (hipEvent pairs on the ctx stream), used by bench.py for the roofline line
     bool prof_on = false;
     struct ProfSlot { const char* name; double total_ms; uint64_t launches; };
@@ -72,6 +72,7 @@ int nae_launch_pv_synth(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig*
 int nae_launch_resample(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig* src, size_t src_len, int ch,
                         size_t n_streams, const float* d_tab, const nae_sig* out, size_t j_begin, size_t j_end);
 int nae_ensure_rs_table(nae_ctx* ctx, double rate_eff);
+int nae_pick_pv_tile(nae_ctx* ctx, size_t frames, size_t n_sc);
 constexpr int kPhasePad = 520; // int32 per (stream-channel, tile) record in the phase workspace
 
 // kernels_nodes.hip

@@ -164,7 +164,7 @@ int stretch_process(nae_stretch* h)
             mid_limit = (long long)1 << 60;
         }
         if (B_r > h->blocks_done) {
-            const int tile = ctx->pv_tile;
+            const int tile = ctx->pv_tile > 0 ? ctx->pv_tile : 64;
             const size_t count = B_r - h->blocks_done;
             int rc = nae_ws_reserve(ctx, &ctx->ws_phase, &ctx->ws_phase_bytes, nae_pv_phase_workspace_bytes(count, ch, 1, tile));
             if (rc) return rc;

@@ -17,8 +17,7 @@ namespace nae {
 struct cf { float x, y; };
 struct __attribute__((packed, aligned(4))) f2u { float x, y; }; // 8-byte access at 4-byte alignment
 
-constexpr int kScratchCf = 576;                 // per-wave LDS scratch, complex elements (8 rows x 72, or 513 natural)
-constexpr int kScratchRow = 72;                 // padded row stride of the transpose images
+constexpr int kScratchCf = 520;                 // per-wave LDS scratch, complex elements (512 for the transposes, 513 natural)
 constexpr int kRingFloats = 4 * NAE_HOP;        // per-wave overlap-add ring: 4 hop blocks
 
 __device__ __forceinline__ void wave_lds_sync()
@@ -71,42 +70,52 @@ __device__ __forceinline__ void load_fft_tw(FftTw& tw, const cf* __restrict__ w5
     tw.b = w64_lds + 8 * (lane & 7);
 }
 
-// bin / packed-sample index held by (lane, register r) after the forward FFT:  k = kl(lane) + 64 r
-__device__ __forceinline__ int kl_of_lane(int lane) { return (lane >> 3) + 8 * (lane & 7); }
+// bin / packed-sample index held by (lane, register r) after the forward FFT:  k = lane + 64 r  (natural order)
+__device__ __forceinline__ int kl_of_lane(int lane) { return lane; }
 
-// canonical forward 512-point FFT.  in: v[j] = z[lane + 64 j];  out: v[r] = Z[kl(lane) + 64 r].
+// canonical forward 512-point FFT.  in: v[j] = z[lane + 64 j];  out: v[r] = Z[lane + 64 r].
+//
+// The two transposes go through the wave's 512-entry LDS scratch with XOR-swizzled addresses chosen so that every
+// ds_write_b64 (16-lane groups, 32 banks) and ds_read_b64 (32-lane groups, 64 banks) is conflict-free WITHOUT
+// padding, and so that pass C leaves the result in natural order (lane = k mod 64):
+//   T1  element u1[q][l]     at  (l ^ (q << 3)) + 64 q
+//   T2  element u2[q][p][m]  at  (q ^ ((m & 3) << 1)) | ((p ^ (m >> 2)) << 3) | (m << 6)
+// (address bits are an invertible GF(2) map of the index bits whose low 4 / 5 bits are a bijection of the
+//  lane bits that vary inside one write / read group).
 __device__ __forceinline__ void fft512_fwd(cf (&v)[8], cf* __restrict__ scratch, const FftTw& tw, int lane)
 {
+    // launder the lane id: the 32 swizzled LDS addresses below are loop-invariant, and hoisting them out of the
+    // frame loop would pin 32 VGPRs; recomputing them costs one v_xor each
+    asm volatile("" : "+v"(lane));
+    const int m = lane & 7, qq = lane >> 3;
     // pass A
     dft8_fwd(v);
 #pragma unroll
     for (int q = 1; q < 8; q++) v[q] = cmul_tw(v[q], tw.a[q - 1]);
-    // transpose 1: u1[q][l] -> lane (m = lane&7, q' = lane>>3) register j = u1[q'][m + 8 j]
+    // transpose 1: u1[q][l] -> lane (m, qq) register j = u1[qq][m + 8 j]
 #pragma unroll
-    for (int q = 0; q < 8; q++) scratch[q * kScratchRow + lane] = v[q];
+    for (int q = 0; q < 8; q++) scratch[(lane ^ (q << 3)) + 64 * q] = v[q];
     wave_lds_sync();
     {
-        const int base = (lane >> 3) * kScratchRow + (lane & 7);
+        const int base = m + 64 * qq;
 #pragma unroll
-        for (int j = 0; j < 8; j++) v[j] = scratch[base + 8 * j];
+        for (int j = 0; j < 8; j++) v[j] = scratch[base + ((j ^ qq) << 3)];
     }
     wave_lds_sync();
     // pass B
     dft8_fwd(v);
 #pragma unroll
     for (int p = 1; p < 8; p++) v[p] = cmul_tw(v[p], tw.b[p]);
-    // transpose 2: u2[q][p][m] -> lane (p'' = lane&7, q'' = lane>>3) register j = u2[q''][p''][j]
+    // transpose 2: u2[qq][p][m] -> lane (q'' = lane & 7, p'' = lane >> 3) register j = u2[q''][p''][j]
     {
-        const int base = (lane >> 3) * kScratchRow + (lane & 7);
+        const int base = (qq ^ ((m & 3) << 1)) | (m << 6);
+        const int ph = m >> 2;
 #pragma unroll
-        for (int p = 0; p < 8; p++) scratch[base + 9 * p] = v[p];
+        for (int p = 0; p < 8; p++) scratch[base | ((p ^ ph) << 3)] = v[p];
     }
     wave_lds_sync();
-    {
-        const int base = (lane >> 3) * kScratchRow + 9 * (lane & 7);
 #pragma unroll
-        for (int j = 0; j < 8; j++) v[j] = scratch[base + j];
-    }
+    for (int j = 0; j < 8; j++) v[j] = scratch[(lane ^ (((j & 3) << 1) | ((j >> 2) << 3))) + 64 * j];
     wave_lds_sync();
     // pass C
     dft8_fwd(v);
