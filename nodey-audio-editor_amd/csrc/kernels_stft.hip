@@ -256,10 +256,22 @@ __global__ __launch_bounds__(kThreads, kOcc) void pv_synth_kernel(SigViewD src, 
     //   half 0: windowed frame -> FFT -> split, phases, phase advance, synthesis spectrum, c2r pre-twiddle
     //   half 1: conj(Z) -> FFT -> windowed overlap-add, emit the completed hop block
     // Frame b0-1 (when it exists) only primes qp.
+    // kOcc == 2 (256 VGPRs): software-pipelined input — frame f+1 is fetched while frame f is computed, so the
+    // HBM/L2 latency of the only global read of the loop is never exposed
+    constexpr bool kPrefetch = (kOcc <= 2);
+    cf nxt[8];
+    const long long f_first = (b0 > 0 ? b0 - 1 : 0);
+    if (kPrefetch && f_first < f_end) load_frame_raw<kUnit>(nxt, in, frame_start(p, f_first), lane);
 #pragma unroll 1
-    for (long long f = (b0 > 0 ? b0 - 1 : 0); f < f_end; f++) {
+    for (long long f = f_first; f < f_end; f++) {
         const long long s = frame_start(p, f);
-        load_frame_windowed<kUnit>(v, in, s, L.hann, lane);
+        if (kPrefetch) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = nxt[j];
+            if (f + 1 < f_end) load_frame_raw<kUnit>(nxt, in, frame_start(p, f + 1), lane);
+            apply_window(v, L.hann, lane);
+        } else
+            load_frame_windowed<kUnit>(v, in, s, L.hann, lane);
 #pragma unroll 1
         for (int half = 0; half < 2; half++) {
             fft512_fwd(v, L.scratch, tw, lane);
@@ -390,15 +402,18 @@ __global__ __launch_bounds__(256) void resample_kernel(SigViewD src, RsParams p,
 // source span it needs (kRsOut*rho + 16 samples per channel) is staged once into LDS with 16-byte loads, the
 // 16 taps are read from LDS, and interleaved stereo output leaves as one 8-byte store per frame.
 constexpr int kRsOut = 1024;                     // output frames per workgroup
+constexpr int kRsRow = 20;                       // LDS row stride of the coefficient table (16 taps + 4 pad): a 64-B
+                                                 // stride maps every row to one of 4 bank slots (4-way conflicts on b128)
 constexpr int kRsMaxSpan = 4096 + 32;            // staged source samples per channel (rho <= 4)
 
 __global__ __launch_bounds__(256) void resample_tile_kernel(SigViewD src, RsParams p, const float* __restrict__ tab,
                                                            OutViewD out, int span_alloc)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char rs_smem[];
-    float* stab = reinterpret_cast<float*>(rs_smem);                           // (PHASES+1) x TAPS
-    float* stage = stab + (NAE_RS_PHASES + 1) * NAE_RS_TAPS;                   // [ch][span_alloc]
-    for (int i = threadIdx.x; i < (NAE_RS_PHASES + 1) * NAE_RS_TAPS; i += 256) stab[i] = tab[i];
+    float* stab = reinterpret_cast<float*>(rs_smem);                           // (PHASES+1) x kRsRow
+    float* stage = stab + (NAE_RS_PHASES + 1) * kRsRow;                        // [ch][span_alloc]
+    for (int i = threadIdx.x; i < (NAE_RS_PHASES + 1) * NAE_RS_TAPS; i += 256)
+        stab[(i / NAE_RS_TAPS) * kRsRow + (i % NAE_RS_TAPS)] = tab[i];
     const long long s = blockIdx.y;
     const long long j0 = p.j_begin + (long long)blockIdx.x * kRsOut;
     long long j1 = j0 + kRsOut;
@@ -445,8 +460,8 @@ __global__ __launch_bounds__(256) void resample_tile_kernel(SigViewD src, RsPara
         const unsigned frac = (unsigned)lo;
         const unsigned ph = frac >> 25;
         const float alpha = (float)(frac & 0x1FFFFFFu) * (1.0f / 33554432.0f);
-        const float4* t0 = reinterpret_cast<const float4*>(stab + ph * NAE_RS_TAPS);
-        const float4* t1 = t0 + NAE_RS_TAPS / 4;
+        const float4* t0 = reinterpret_cast<const float4*>(stab + ph * kRsRow);
+        const float4* t1 = reinterpret_cast<const float4*>(stab + (ph + 1) * kRsRow);
         float coef[NAE_RS_TAPS];
 #pragma unroll
         for (int q = 0; q < NAE_RS_TAPS / 4; q++) {
@@ -609,7 +624,7 @@ int nae_launch_resample(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig*
     const long long span_need = (long long)(kRsOut * rho) + NAE_RS_TAPS + 8;
     const bool tiled = span_need <= kRsMaxSpan && !getenv("NAE_RS_DIRECT");
     const int span_alloc = (int)((span_need + 3) & ~3ll);
-    const size_t lds = ((NAE_RS_PHASES + 1) * NAE_RS_TAPS + (size_t)ch * span_alloc) * sizeof(float);
+    const size_t lds = ((NAE_RS_PHASES + 1) * kRsRow + (size_t)ch * span_alloc) * sizeof(float);
     const unsigned gx = tiled ? (unsigned)((count + kRsOut - 1) / kRsOut) : (unsigned)((count + 255) / 256);
     // blockIdx.y is limited to 65535
     for (size_t s0 = 0; s0 < n_streams; s0 += 65535) {

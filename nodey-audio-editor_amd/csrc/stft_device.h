@@ -186,12 +186,11 @@ struct ChanView {
     long long len;  // valid sample-frames: indices outside [0, len) read as zero
 };
 
-// load + window one frame in FFT input layout: v[j] = (x[s+2n] w[2n], x[s+2n+1] w[2n+1]), n = lane + 64 j.
+// load one frame in FFT input layout, un-windowed: v[j] = (x[s+2n], x[s+2n+1]), n = lane + 64 j.
 // `s` and `in` are wave-uniform, so the interior/boundary choice is a scalar branch and the interior path
 // addresses with a scalar base + 32-bit lane offset.  kUnit: frame stride 1 (planar source) -> 8-byte loads.
 template <bool kUnit>
-__device__ __forceinline__ void load_frame_windowed(cf (&v)[8], const ChanView& in, long long s,
-                                                    const float* __restrict__ hann_lds, int lane)
+__device__ __forceinline__ void load_frame_raw(cf (&v)[8], const ChanView& in, long long s, int lane)
 {
     const bool interior = (s >= 0) && (s + NAE_FFT_N <= in.len);
     if (interior) {
@@ -219,11 +218,23 @@ __device__ __forceinline__ void load_frame_windowed(cf (&v)[8], const ChanView& 
             v[j].y = (i0 + 1 >= 0 && i0 + 1 < in.len) ? in.p[(i0 + 1) * in.fs] : 0.0f;
         }
     }
+}
+
+__device__ __forceinline__ void apply_window(cf (&v)[8], const float* __restrict__ hann_lds, int lane)
+{
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         const float2 w = *reinterpret_cast<const float2*>(hann_lds + 2 * (lane + 64 * j));
         v[j] = cf{v[j].x * w.x, v[j].y * w.y};
     }
+}
+
+template <bool kUnit>
+__device__ __forceinline__ void load_frame_windowed(cf (&v)[8], const ChanView& in, long long s,
+                                                    const float* __restrict__ hann_lds, int lane)
+{
+    load_frame_raw<kUnit>(v, in, s, lane);
+    apply_window(v, hann_lds, lane);
 }
 
 } // namespace nae
