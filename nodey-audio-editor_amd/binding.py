@@ -35,7 +35,8 @@ class NaeError(RuntimeError):
 
 
 def lib_path() -> str:
-    return os.path.join(_HERE, "libnae_gpu.so")
+    # NAE_GPU_LIB selects another build of the same ABI (A/B timing of kernel variants on one GPU box)
+    return os.environ.get("NAE_GPU_LIB") or os.path.join(_HERE, "libnae_gpu.so")
 
 
 def build_library(verbose: bool = False) -> str:

@@ -202,12 +202,15 @@ __device__ __forceinline__ void load_frame_raw(cf (&v)[8], const ChanView& in, l
                 v[j] = cf{t.x, t.y};
             }
         } else {
+            // strided source (interleaved stereo: fs = 2): ONE vector multiply for the lane offset; the per-j part
+            // of the address is wave-uniform and stays in scalar registers (v_mul_lo_u32 is quarter rate)
             const int fs = (int)in.fs;
+            const int lane_off = 2 * lane * fs;
             const float* base = in.p + s * in.fs;
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                const int n2 = 2 * (lane + 64 * j);
-                v[j] = cf{base[n2 * fs], base[(n2 + 1) * fs]};
+                const float* bj = base + (long long)(128 * j) * fs;
+                v[j] = cf{bj[lane_off], bj[lane_off + fs]};
             }
         }
     } else {

@@ -9,7 +9,7 @@ import sys
 src = sys.argv[1]
 out = "/tmp/isa_%d.s" % os.getpid()
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
-                "-S", "--cuda-device-only", "-o", out, src], check=True, stderr=subprocess.DEVNULL)
+                "-fno-slp-vectorize", "-S", "--cuda-device-only", "-o", out, src], check=True, stderr=subprocess.DEVNULL)
 s = open(out).read()
 labels = [(m.start(), m.group(1)) for m in re.finditer(r"^(_Z\w+):", s, re.M) if "kernel" in m.group(1)]
 for i, (pos, name) in enumerate(labels):
