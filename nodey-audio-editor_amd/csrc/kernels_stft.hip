@@ -274,7 +274,7 @@ __global__ __launch_bounds__(kThreads, kOcc) void pv_synth_kernel(SigViewD src, 
             load_frame_windowed<kUnit>(v, in, s, L.hann, lane);
 #pragma unroll 1
         for (int half = 0; half < 2; half++) {
-            fft512_fwd(v, L.scratch, tw, lane);
+            fft512_fwd<(kOcc > 2)>(v, L.scratch, tw, lane);
             if (half == 0) {
                 const cf nyq = rfft_split(v, L.scratch, L.t1024, lane);
                 uint32_t qa[9];
@@ -294,18 +294,20 @@ __global__ __launch_bounds__(kThreads, kOcc) void pv_synth_kernel(SigViewD src, 
                 s_prev = s;
                 if (f < b0) break;
                 // ---- synthesis spectrum Y = |X| e^{2 pi i qs}, natural order (tolerance path from here)
+                // |X| e^{i qs} == X e^{i (qs - qa)}: rotate by the phase DIFFERENCE (no sqrt; the 5.5e-8-turn error
+                // of the polynomial arctangent only perturbs the result by ~3e-7 relative — tolerance path)
 #pragma unroll
                 for (int r = 0; r < 8; r++) {
-                    const float mag = __builtin_amdgcn_sqrtf(__builtin_fmaf(v[r].x, v[r].x, v[r].y * v[r].y));
-                    const float ph = (float)(int32_t)qs[r] * (1.0f / 4294967296.0f);
-                    cf y{mag * __builtin_amdgcn_cosf(ph), mag * __builtin_amdgcn_sinf(ph)};
+                    const float ph = (float)(int32_t)(qs[r] - qa[r]) * (1.0f / 4294967296.0f);
+                    const float c = __builtin_amdgcn_cosf(ph), s = __builtin_amdgcn_sinf(ph);
+                    cf y{__builtin_fmaf(v[r].x, c, -(v[r].y * s)), __builtin_fmaf(v[r].x, s, v[r].y * c)};
                     if (r == 0 && lane == 0) y.y = 0.0f; // c2r ignores Im Y[0]
                     L.scratch[kl + 64 * r] = y;
                 }
                 if (lane == 0) {
-                    const float mag = __builtin_amdgcn_sqrtf(__builtin_fmaf(nyq.x, nyq.x, nyq.y * nyq.y));
-                    const float ph = (float)(int32_t)qs[8] * (1.0f / 4294967296.0f);
-                    L.scratch[512] = cf{mag * __builtin_amdgcn_cosf(ph), 0.0f};
+                    const float ph = (float)(int32_t)(qs[8] - qa[8]) * (1.0f / 4294967296.0f);
+                    const float c = __builtin_amdgcn_cosf(ph), s = __builtin_amdgcn_sinf(ph);
+                    L.scratch[512] = cf{__builtin_fmaf(nyq.x, c, -(nyq.y * s)), 0.0f};
                 }
                 wave_lds_sync();
                 // ---- c2r pre-twiddle into FFT input layout, conjugated (inverse = conj(FFT(conj Z)) / 512)

@@ -82,11 +82,13 @@ __device__ __forceinline__ int kl_of_lane(int lane) { return lane; }
 //   T2  element u2[q][p][m]  at  (q ^ ((m & 3) << 1)) | ((p ^ (m >> 2)) << 3) | (m << 6)
 // (address bits are an invertible GF(2) map of the index bits whose low 4 / 5 bits are a bijection of the
 //  lane bits that vary inside one write / read group).
+template <bool kLaunder = true>
 __device__ __forceinline__ void fft512_fwd(cf (&v)[8], cf* __restrict__ scratch, const FftTw& tw, int lane)
 {
-    // launder the lane id: the 32 swizzled LDS addresses below are loop-invariant, and hoisting them out of the
-    // frame loop would pin 32 VGPRs; recomputing them costs one v_xor each
-    asm volatile("" : "+v"(lane));
+    // kLaunder: the 32 swizzled LDS addresses below are loop-invariant, and hoisting them out of the frame loop
+    // pins 32 VGPRs; at 128 VGPRs that spills, so the lane id is laundered and they are recomputed (~75
+    // instructions per FFT).  The 256-VGPR build keeps them hoisted.
+    if (kLaunder) asm volatile("" : "+v"(lane));
     const int m = lane & 7, qq = lane >> 3;
     // pass A
     dft8_fwd(v);
