@@ -18,11 +18,18 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def norm(name):
+    """'void nae::pv_synth_kernel<true, 2>(nae::SigViewD, ...)' -> 'pv_synth_kernel'"""
+    import re
+    name = name.split("(")[0].replace("void ", "").replace("nae::", "").strip()
+    return re.sub(r"<.*", "", name)
+
+
 def per_kernel(path):
     d = collections.defaultdict(list)
     meta = {}
     for r in csv.DictReader(open(path)):
-        k = r["Kernel_Name"].split("(")[0].replace("nae::", "")
+        k = norm(r["Kernel_Name"])
         d[k].append(float(r["Counter_Value"]))
         meta[k] = {"vgpr": int(r["VGPR_Count"]), "lds": int(r["LDS_Block_Size"]), "wg": int(r["Workgroup_Size"])}
     return {k: sorted(v)[len(v) // 2] for k, v in d.items()}, meta
@@ -37,7 +44,7 @@ def main():
     w, _ = per_kernel(write)
     dur = {}
     for r in csv.DictReader(open(stats)):
-        dur[r["Name"].split("(")[0].replace("nae::", "")] = float(r["AverageNs"]) / 1e6
+        dur[norm(r["Name"])] = dur.get(norm(r["Name"]), 0.0) + float(r["AverageNs"]) / 1e6
     traffic = {}
     lines = [f"# {tag}: HBM traffic per launch from rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes)", "",
              f"sample-frames per launch: {sf}", "",
