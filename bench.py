@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--streams", type=int, default=1024, help="streams per GPU (C5: 1024)")
     ap.add_argument("--seconds", type=float, default=10.0, help="length of every stream at 48 kHz (C5: 10 s)")
-    ap.add_argument("--cpu-streams", type=int, default=48, help="streams the CPU-oracle baseline is timed on")
+    ap.add_argument("--cpu-streams", type=int, default=128, help="streams the CPU-oracle baseline is timed on")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     return ap.parse_args()
