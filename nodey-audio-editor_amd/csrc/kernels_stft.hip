@@ -118,17 +118,29 @@ __device__ __forceinline__ cf analyse(cf (&v)[8], const ChanView& in, long long 
     return rfft_split(v, L.scratch, L.t1024, lane);
 }
 
+// NAE_ABL_* macros: timing-only ablation builds for tools/ab.sh (wrong results by construction; never shipped)
 __device__ __forceinline__ void phases_of(const cf (&v)[8], cf nyq, uint32_t (&qa)[9])
 {
+#ifdef NAE_ABL_NO_ATAN2
+#pragma unroll
+    for (int r = 0; r < 8; r++) qa[r] = __float_as_uint(v[r].y) ^ __float_as_uint(v[r].x);
+    qa[8] = __float_as_uint(nyq.y) ^ __float_as_uint(nyq.x);
+#else
 #pragma unroll
     for (int r = 0; r < 8; r++) qa[r] = atan2_q32(v[r].y, v[r].x);
     qa[8] = atan2_q32(nyq.y, nyq.x);
+#endif
 }
 
 // phase increment of one hop for this lane's 9 bins (integer, exact)
 __device__ __forceinline__ void phase_inc(const uint32_t (&qa)[9], const uint32_t (&qp)[9], uint32_t (&acc)[9],
                                           int kl, unsigned d, unsigned R)
 {
+#ifdef NAE_ABL_NO_PHASEINC
+#pragma unroll
+    for (int r = 0; r < 9; r++) acc[r] += qa[r] - qp[r] + d + R;
+    return;
+#endif
 #pragma unroll
     for (int r = 0; r < 9; r++) {
         const unsigned k = (r < 8) ? (unsigned)(kl + 64 * r) : 512u;
@@ -298,9 +310,13 @@ __global__ __launch_bounds__(kThreads, kOcc) void pv_synth_kernel(SigViewD src, 
                 // of the polynomial arctangent only perturbs the result by ~3e-7 relative — tolerance path)
 #pragma unroll
                 for (int r = 0; r < 8; r++) {
+#ifdef NAE_ABL_NO_ROTATE
+                    cf y{v[r].x + __uint_as_float(qs[r] - qa[r]), v[r].y};
+#else
                     const float ph = (float)(int32_t)(qs[r] - qa[r]) * (1.0f / 4294967296.0f);
                     const float c = __builtin_amdgcn_cosf(ph), s = __builtin_amdgcn_sinf(ph);
                     cf y{__builtin_fmaf(v[r].x, c, -(v[r].y * s)), __builtin_fmaf(v[r].x, s, v[r].y * c)};
+#endif
                     if (r == 0 && lane == 0) y.y = 0.0f; // c2r ignores Im Y[0]
                     L.scratch[kl + 64 * r] = y;
                 }
@@ -408,12 +424,15 @@ constexpr int kRsRow = 20;                       // LDS row stride of the coeffi
                                                  // stride maps every row to one of 4 bank slots (4-way conflicts on b128)
 constexpr int kRsMaxSpan = 4096 + 32;            // staged source samples per channel (rho <= 4)
 
+// kStereo: the two channels are staged INTERLEAVED in LDS so one ds_read_b64 per tap feeds both accumulators
+// (the tap reads, not HBM, bound this kernel: 16 per channel-output).
+template <bool kStereo>
 __global__ __launch_bounds__(256) void resample_tile_kernel(SigViewD src, RsParams p, const float* __restrict__ tab,
                                                            OutViewD out, int span_alloc)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char rs_smem[];
     float* stab = reinterpret_cast<float*>(rs_smem);                           // (PHASES+1) x kRsRow
-    float* stage = stab + (NAE_RS_PHASES + 1) * kRsRow;                        // [ch][span_alloc]
+    float* stage = stab + (NAE_RS_PHASES + 1) * kRsRow;                        // stereo: [span_alloc][2]; else [ch][span_alloc]
     for (int i = threadIdx.x; i < (NAE_RS_PHASES + 1) * NAE_RS_TAPS; i += 256)
         stab[(i / NAE_RS_TAPS) * kRsRow + (i % NAE_RS_TAPS)] = tab[i];
     const long long s = blockIdx.y;
@@ -428,24 +447,42 @@ __global__ __launch_bounds__(256) void resample_tile_kernel(SigViewD src, RsPara
     const long long m_lo = (idx_first - (NAE_RS_TAPS / 2 - 1)) & ~3ll;          // floor to 4 (arithmetic on negatives too)
     const long long m_hi = idx_last + NAE_RS_TAPS / 2 + 1;
     const int span = (int)(m_hi - m_lo);
-    for (int c = 0; c < p.ch; c++) {
-        const float* v = src.base + s * src.ss + c * src.cs;
-        float* st = stage + c * span_alloc;
-        const bool vec = (src.fs == 1) && ((reinterpret_cast<uintptr_t>(v) & 15) == 0);
+    const float* v0 = src.base + s * src.ss;
+    if (kStereo) {
+        const float* v1 = v0 + src.cs;
+        const bool vec = (src.fs == 1) && (((reinterpret_cast<uintptr_t>(v0) | reinterpret_cast<uintptr_t>(v1)) & 15) == 0);
         if (vec) {
             for (int i = 4 * threadIdx.x; i < span; i += 4 * 256) {
                 const long long m = m_lo + i;
-                float4 x;
-                if (m >= 0 && m + 4 <= p.src_len) x = *reinterpret_cast<const float4*>(v + m);
-                else {
-                    x.x = (m + 0 >= 0 && m + 0 < p.src_len) ? v[m + 0] : 0.0f;
-                    x.y = (m + 1 >= 0 && m + 1 < p.src_len) ? v[m + 1] : 0.0f;
-                    x.z = (m + 2 >= 0 && m + 2 < p.src_len) ? v[m + 2] : 0.0f;
-                    x.w = (m + 3 >= 0 && m + 3 < p.src_len) ? v[m + 3] : 0.0f;
+                float4 x, y;
+                if (m >= 0 && m + 4 <= p.src_len) {
+                    x = *reinterpret_cast<const float4*>(v0 + m);
+                    y = *reinterpret_cast<const float4*>(v1 + m);
+                } else {
+                    float xe[4], ye[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const bool ok = (m + e >= 0) && (m + e < p.src_len);
+                        xe[e] = ok ? v0[m + e] : 0.0f;
+                        ye[e] = ok ? v1[m + e] : 0.0f;
+                    }
+                    x = float4{xe[0], xe[1], xe[2], xe[3]};
+                    y = float4{ye[0], ye[1], ye[2], ye[3]};
                 }
-                *reinterpret_cast<float4*>(st + i) = x;
+                *reinterpret_cast<float4*>(stage + 2 * i) = float4{x.x, y.x, x.y, y.y};
+                *reinterpret_cast<float4*>(stage + 2 * i + 4) = float4{x.z, y.z, x.w, y.w};
             }
         } else {
+            for (int i = threadIdx.x; i < span; i += 256) {
+                const long long m = m_lo + i;
+                const bool ok = m >= 0 && m < p.src_len;
+                *reinterpret_cast<float2*>(stage + 2 * i) = float2{ok ? v0[m * src.fs] : 0.0f, ok ? v1[m * src.fs] : 0.0f};
+            }
+        }
+    } else {
+        for (int c = 0; c < p.ch; c++) {
+            const float* v = v0 + c * src.cs;
+            float* st = stage + c * span_alloc;
             for (int i = threadIdx.x; i < span; i += 256) {
                 const long long m = m_lo + i;
                 st[i] = (m >= 0 && m < p.src_len) ? v[m * src.fs] : 0.0f;
@@ -453,7 +490,7 @@ __global__ __launch_bounds__(256) void resample_tile_kernel(SigViewD src, RsPara
         }
     }
     __syncthreads();
-    const bool out_pair = (p.ch == 2) && (out.cs == 1) && (out.fs == 2) &&
+    const bool out_pair = kStereo && (out.cs == 1) && (out.fs == 2) &&
                           ((reinterpret_cast<uintptr_t>(out.base + s * out.ss) & 7) == 0);
     for (long long j = j0 + threadIdx.x; j < j1; j += 256) {
         const unsigned long long lo = (unsigned long long)j * p.step_q32;
@@ -475,12 +512,22 @@ __global__ __launch_bounds__(256) void resample_tile_kernel(SigViewD src, RsPara
         }
         const int o = (int)(idx - (NAE_RS_TAPS / 2 - 1) - m_lo);
         float acc[2] = {0.0f, 0.0f};
-        for (int c = 0; c < p.ch; c++) {
-            const float* st = stage + c * span_alloc + o;
-            float a = 0.0f;
+        if (kStereo) {
+            const float2* st = reinterpret_cast<const float2*>(stage) + o;
 #pragma unroll
-            for (int i = 0; i < NAE_RS_TAPS; i++) a += coef[i] * st[i];
-            acc[c] = a;
+            for (int i = 0; i < NAE_RS_TAPS; i++) {
+                const float2 x = st[i];
+                acc[0] += coef[i] * x.x;
+                acc[1] += coef[i] * x.y;
+            }
+        } else {
+            for (int c = 0; c < p.ch; c++) {
+                const float* st = stage + c * span_alloc + o;
+                float a = 0.0f;
+#pragma unroll
+                for (int i = 0; i < NAE_RS_TAPS; i++) a += coef[i] * st[i];
+                acc[c] = a;
+            }
         }
         if (out_pair) {
             *reinterpret_cast<float2*>(out.base + s * out.ss + 2 * j) = float2{acc[0], acc[1]};
@@ -635,8 +682,11 @@ int nae_launch_resample(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig*
         OutViewD ov = to_out(out);
         sv.base += (long long)s0 * sv.ss;
         ov.base += (long long)s0 * ov.ss;
-        if (tiled)
-            NAE_KLAUNCH(ctx, "resample_tile_kernel", resample_tile_kernel, dim3(gx, (unsigned)ns), dim3(256), lds, ctx->stream,
+        if (tiled && ch == 2)
+            NAE_KLAUNCH(ctx, "resample_tile_kernel", (resample_tile_kernel<true>), dim3(gx, (unsigned)ns), dim3(256), lds, ctx->stream,
+                        sv, p, d_tab, ov, span_alloc);
+        else if (tiled)
+            NAE_KLAUNCH(ctx, "resample_tile_kernel", (resample_tile_kernel<false>), dim3(gx, (unsigned)ns), dim3(256), lds, ctx->stream,
                         sv, p, d_tab, ov, span_alloc);
         else
             NAE_KLAUNCH(ctx, "resample_kernel", resample_kernel, dim3(gx, (unsigned)ns), dim3(256), 0, ctx->stream, sv, p,

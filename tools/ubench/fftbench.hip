@@ -45,6 +45,50 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, kOcc) void bench_kernel(const 
                 v[r] = cf{mag * __builtin_amdgcn_cosf(ph), mag * __builtin_amdgcn_sinf(ph)};
             }
         }
+        if (kStage == 10) {   // phase_inc alone (9 bins)
+#pragma unroll
+            for (int r = 0; r < 9; r++) {
+                const unsigned k = (r < 8) ? (unsigned)(lane + 64 * r) : 512u;
+                const unsigned d = 215u + (it & 1), R = 19976592u - (it & 1) * 92484u;
+                const uint32_t qa = __float_as_uint(v[r & 7].x), qp = __float_as_uint(v[r & 7].y);
+                const uint32_t e = ((k * d) & 1023u) << 22;
+                const int32_t dw = (int32_t)(qa - qp - e);
+                const uint32_t adv = ((k * 256u) & 1023u) << 22;
+                const long long scaled = ((long long)dw * (long long)R + (1ll << 23)) >> 24;
+                acc += adv + (uint32_t)scaled;
+            }
+        }
+        if (kStage == 11) {   // atan2 alone (9 bins)
+#pragma unroll
+            for (int r = 0; r < 8; r++) acc += atan2_q32(v[r].y, v[r].x);
+            acc += atan2_q32(v[0].x, v[1].y);
+        }
+        if (kStage == 12) {   // rotate by phase difference (9 bins): cvt, sin, cos, 4 flops
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const float ph = (float)(int32_t)(acc + r * 7919u) * (1.0f / 4294967296.0f);
+                const float c = __builtin_amdgcn_cosf(ph), sn = __builtin_amdgcn_sinf(ph);
+                v[r] = cf{__builtin_fmaf(v[r].x, c, -(v[r].y * sn)), __builtin_fmaf(v[r].x, sn, v[r].y * c)};
+            }
+            acc += __float_as_uint(v[3].x);
+        }
+        if (kStage == 13) {   // c2r pre-twiddle: natural write, natural + mirrored read, table read
+#pragma unroll
+            for (int r = 0; r < 8; r++) scratch[lane + 64 * r] = v[r];
+            if (lane == 0) scratch[512] = v[0];
+            wave_lds_sync();
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int k = lane + 64 * r;
+                const cf Xk = scratch[k], Xm = scratch[512 - k];
+                const cf T = t1024[k];
+                const cf E{0.5f * (Xk.x + Xm.x), 0.5f * (Xk.y - Xm.y)};
+                const cf D{0.5f * (Xk.x - Xm.x), 0.5f * (Xk.y + Xm.y)};
+                const cf Q{__builtin_fmaf(T.x, D.x, T.y * D.y), __builtin_fmaf(T.x, D.y, -(T.y * D.x))};
+                v[r] = cf{E.x - Q.y, -(E.y + Q.x)};
+            }
+            wave_lds_sync();
+        }
         if (kStage == 0) {
 #pragma unroll
             for (int r = 0; r < 8; r++) v[r] = cf{v[r].x * 1.0001f + 0.5f, v[r].y * 0.9999f - 0.5f};
@@ -95,6 +139,10 @@ int main()
     hipMemcpy(dt, t1024.data(), 520 * 8, hipMemcpyHostToDevice);
     hipMemcpy(dh, hann.data(), 4096, hipMemcpyHostToDevice);
     run<0, 8, 2>("trivial loop, 8 w/CU", dw, dt, dh, dout, 1);
+    run<10, 8, 2>("phase_inc x9, 8 w/CU", dw, dt, dh, dout, 1);
+    run<11, 8, 2>("atan2 x9, 8 w/CU", dw, dt, dh, dout, 1);
+    run<12, 8, 2>("rotate x8, 8 w/CU", dw, dt, dh, dout, 1);
+    run<13, 8, 2>("c2r pretwiddle, 8 w/CU", dw, dt, dh, dout, 1);
     run<1, 8, 2>("fft only, 8 w/CU", dw, dt, dh, dout, 1);
     run<1, 8, 4>("fft only, 16 w/CU", dw, dt, dh, dout, 2);
     run<1, 4, 1>("fft only, 4 w/CU", dw, dt, dh, dout, 1);
