@@ -164,6 +164,8 @@ typedef struct nae_stretch_plan {
     uint32_t r_q24[2];
     uint64_t step_q32;
     size_t out_len, mid_len, frames;
+    int rs_first;             /* both stages on and rate_eff > 1: the transposer runs FIRST (fewer samples reach the
+                                 vocoder; SoundTouch orders its stages by the same rule) and mid_len is ITS output */
 } nae_stretch_plan;
 int nae_stretch_plan_make(double rate, double pitch, size_t in_len, nae_stretch_plan* plan);
 

@@ -70,7 +70,7 @@ class Sig(C.Structure):
 class StretchPlan(C.Structure):
     _fields_ = [("pv_on", C.c_int), ("rs_on", C.c_int), ("tempo_eff", C.c_double), ("rate_eff", C.c_double),
                 ("ha_q24", C.c_int64), ("d0", C.c_int32), ("r_q24", C.c_uint32 * 2), ("step_q32", C.c_uint64),
-                ("out_len", C.c_size_t), ("mid_len", C.c_size_t), ("frames", C.c_size_t)]
+                ("out_len", C.c_size_t), ("mid_len", C.c_size_t), ("frames", C.c_size_t), ("rs_first", C.c_int)]
 
 
 class Graph4(C.Structure):

@@ -704,11 +704,10 @@ int nae_launch_pv_synth(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig*
     return nae_check(ctx, hipGetLastError(), "pv_synth_kernel");
 }
 
-// outputs [j_begin, j_end) (whole plan when j_end == 0)
+// outputs [j_begin, j_end)
 int nae_launch_resample(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig* src, size_t src_len, int ch,
                         size_t n_streams, const float* d_tab, const nae_sig* out, size_t j_begin, size_t j_end)
 {
-    if (j_end == 0) j_end = pl->out_len;
     if (j_end <= j_begin || n_streams == 0) return NAE_OK;
     RsParams p{pl->step_q32, (long long)src_len, (long long)j_end, ch, (long long)j_begin};
     const size_t count = j_end - j_begin;

@@ -354,15 +354,23 @@ int nae_stretch_plan_make(double rate, double pitch, size_t in_len, nae_stretch_
     }
     pl->step_q32 = (uint64_t)llround(rho * 4294967296.0);
     pl->out_len = (size_t)floor((double)in_len / (tempo * rho) + 0.5);
-    if (pl->rs_on) {
+    pl->rs_first = pl->pv_on && pl->rs_on && rho > 1.0;
+    size_t pv_out;
+    if (pl->rs_first) {
+        pl->mid_len = (size_t)floor((double)in_len / rho + 0.5);
+        pv_out = pl->out_len;
+    } else if (pl->rs_on) {
         if (pl->out_len == 0) pl->mid_len = 0;
         else {
             const unsigned __int128 pos = (unsigned __int128)(pl->out_len - 1) * pl->step_q32;
             pl->mid_len = (size_t)(pos >> 32) + NAE_RS_TAPS / 2 + 1;
         }
-    } else
+        pv_out = pl->mid_len;
+    } else {
         pl->mid_len = pl->out_len;
-    pl->frames = pl->pv_on ? (pl->mid_len + NAE_FFT_N / 2 + NAE_HOP - 1) / NAE_HOP + 1 : 0;
+        pv_out = pl->out_len;
+    }
+    pl->frames = pl->pv_on ? (pv_out + NAE_FFT_N / 2 + NAE_HOP - 1) / NAE_HOP + 1 : 0;
     return NAE_OK;
 }
 
@@ -385,32 +393,45 @@ int nae_stretch_block_f32(nae_ctx* ctx, double rate, double pitch, const nae_sig
     if (n_streams == 0 || pl.out_len == 0) return NAE_OK;
     if (!pl.pv_on && !pl.rs_on) return nae_launch_copy_sig(ctx, src, dst, in_len, ch, n_streams, false, 1.0f);
 
-    const nae_sig* rs_src = src;
-    size_t rs_src_len = in_len;
+    const size_t mid_stride = (pl.mid_len + 3) & ~(size_t)3;
     nae_sig mid{};
-    if (pl.pv_on) {
-        const int tile = nae_pick_pv_tile(ctx, pl.frames, n_streams * ch);
-        rc = nae_ws_reserve(ctx, &ctx->ws_phase, &ctx->ws_phase_bytes, nae_pv_phase_workspace_bytes(pl.frames, ch, n_streams, tile));
+    if (pl.pv_on && pl.rs_on) {
+        rc = nae_ws_reserve(ctx, &ctx->ws_mid, &ctx->ws_mid_bytes, n_streams * ch * mid_stride * sizeof(float));
         if (rc) return rc;
-        const nae_sig* pv_out = dst;
-        if (pl.rs_on) {
-            const size_t mid_stride = (pl.mid_len + 3) & ~(size_t)3;
-            rc = nae_ws_reserve(ctx, &ctx->ws_mid, &ctx->ws_mid_bytes, n_streams * ch * mid_stride * sizeof(float));
-            if (rc) return rc;
-            mid = nae_sig{ctx->ws_mid, (size_t)ch * mid_stride, mid_stride, 1};
-            pv_out = &mid;
-            rs_src = &mid;
-            rs_src_len = pl.mid_len;
-        }
-        rc = nae_launch_pv_phase(ctx, &pl, src, in_len, ch, n_streams, tile, static_cast<uint32_t*>(ctx->ws_phase), nullptr);
-        if (rc) return rc;
-        rc = nae_launch_pv_synth(ctx, &pl, src, in_len, ch, n_streams, tile, static_cast<const uint32_t*>(ctx->ws_phase), pv_out, nullptr);
-        if (rc) return rc;
+        mid = nae_sig{ctx->ws_mid, (size_t)ch * mid_stride, mid_stride, 1};   // planar: 16-byte accesses on both sides
     }
     if (pl.rs_on) {
         rc = nae_ensure_rs_table(ctx, pl.rate_eff);
         if (rc) return rc;
-        rc = nae_launch_resample(ctx, &pl, rs_src, rs_src_len, ch, n_streams, ctx->d_rs_tab, dst, 0, 0);
+    }
+    // stage order: transposer first when it shrinks the signal (rate_eff > 1), else vocoder first
+    const nae_sig* pv_src = src;
+    size_t pv_in_len = in_len;
+    const nae_sig* pv_dst = dst;
+    long long pv_out_len = (long long)pl.out_len;
+    if (pl.rs_first) {
+        rc = nae_launch_resample(ctx, &pl, src, in_len, ch, n_streams, ctx->d_rs_tab, &mid, 0, pl.mid_len);
+        if (rc) return rc;
+        pv_src = &mid;
+        pv_in_len = pl.mid_len;
+    } else if (pl.pv_on && pl.rs_on) {
+        pv_dst = &mid;
+        pv_out_len = (long long)pl.mid_len;
+    }
+    if (pl.pv_on) {
+        const int tile = nae_pick_pv_tile(ctx, pl.frames, n_streams * ch);
+        rc = nae_ws_reserve(ctx, &ctx->ws_phase, &ctx->ws_phase_bytes, nae_pv_phase_workspace_bytes(pl.frames, ch, n_streams, tile));
+        if (rc) return rc;
+        nae_pv_segment seg{0, (long long)pl.frames, (long long)pl.frames, pv_out_len, nullptr, nullptr};
+        rc = nae_launch_pv_phase(ctx, &pl, pv_src, pv_in_len, ch, n_streams, tile, static_cast<uint32_t*>(ctx->ws_phase), &seg);
+        if (rc) return rc;
+        rc = nae_launch_pv_synth(ctx, &pl, pv_src, pv_in_len, ch, n_streams, tile, static_cast<const uint32_t*>(ctx->ws_phase), pv_dst, &seg);
+        if (rc) return rc;
+    }
+    if (pl.rs_on && !pl.rs_first) {
+        const nae_sig* rs_src = pl.pv_on ? &mid : src;
+        const size_t rs_src_len = pl.pv_on ? pl.mid_len : in_len;
+        rc = nae_launch_resample(ctx, &pl, rs_src, rs_src_len, ch, n_streams, ctx->d_rs_tab, dst, 0, pl.out_len);
         if (rc) return rc;
     }
     return NAE_OK;
@@ -436,7 +457,23 @@ int nae_debug_pv_tile_phase(nae_ctx* ctx, double rate, double pitch, const nae_s
     const size_t ws_bytes = nae_pv_phase_workspace_bytes(pl.frames, ch, n_streams, tile);
     rc = nae_ws_reserve(ctx, &ctx->ws_phase, &ctx->ws_phase_bytes, ws_bytes);
     if (rc) return rc;
-    rc = nae_launch_pv_phase(ctx, &pl, src, in_len, ch, n_streams, tile, static_cast<uint32_t*>(ctx->ws_phase), nullptr);
+    const nae_sig* pv_src = src;
+    size_t pv_in_len = in_len;
+    nae_sig mid{};
+    if (pl.rs_first) {
+        const size_t mid_stride = (pl.mid_len + 3) & ~(size_t)3;
+        rc = nae_ws_reserve(ctx, &ctx->ws_mid, &ctx->ws_mid_bytes, n_streams * ch * mid_stride * sizeof(float));
+        if (rc) return rc;
+        mid = nae_sig{ctx->ws_mid, (size_t)ch * mid_stride, mid_stride, 1};
+        rc = nae_ensure_rs_table(ctx, pl.rate_eff);
+        if (rc) return rc;
+        rc = nae_launch_resample(ctx, &pl, src, in_len, ch, n_streams, ctx->d_rs_tab, &mid, 0, pl.mid_len);
+        if (rc) return rc;
+        pv_src = &mid;
+        pv_in_len = pl.mid_len;
+    }
+    nae_pv_segment seg{0, (long long)pl.frames, (long long)pl.frames, 0, nullptr, nullptr};
+    rc = nae_launch_pv_phase(ctx, &pl, pv_src, pv_in_len, ch, n_streams, tile, static_cast<uint32_t*>(ctx->ws_phase), &seg);
     if (rc) return rc;
     std::vector<int32_t> tmp(ws_bytes / sizeof(int32_t));
     hipError_t e = hipMemcpyAsync(tmp.data(), ctx->ws_phase, ws_bytes, hipMemcpyDeviceToHost, ctx->stream);

@@ -150,6 +150,71 @@ int stretch_process(nae_stretch* h)
         }
         return NAE_OK;
     }
+    // ---- transposer first (rate_eff > 1): in -> [RS] -> mid (interleaved FIFO) -> [PV] -> out
+    if (pl.rs_first) {
+        size_t J_r;
+        if (h->flushed) J_r = fin.mid_len;
+        else if (h->in_total <= NAE_RS_TAPS / 2) J_r = 0;
+        else {
+            const unsigned __int128 lim = ((unsigned __int128)(h->in_total - NAE_RS_TAPS / 2) << 32) - 1;
+            J_r = (size_t)(lim / pl.step_q32) + 1;
+        }
+        if (J_r > h->mid_total) {
+            int rc = nae_ensure_rs_table(ctx, pl.rate_eff);
+            if (rc) return rc;
+            rc = fifo_reserve_interleaved(ctx, h->mid, h->mid_total, J_r, ch);
+            if (rc) return rc;
+            nae_sig src{h->in.cur.p - (ptrdiff_t)h->in.base * ch, 0, 1, (size_t)ch};
+            nae_sig dst{h->mid.cur.p - (ptrdiff_t)h->mid.base * ch, 0, 1, (size_t)ch};
+            rc = nae_launch_resample(ctx, &pl, &src, h->in_total, ch, 1, ctx->d_rs_tab, &dst, h->mid_total, J_r);
+            if (rc) return rc;
+            h->mid_total = J_r;
+            const unsigned __int128 pos = (unsigned __int128)J_r * pl.step_q32;
+            const long long need_from = ((long long)(pos >> 32) - (NAE_RS_TAPS / 2 - 1)) & ~3ll;
+            const size_t nb = need_from > 0 ? (size_t)need_from : 0;
+            rc = fifo_drop_interleaved(ctx, h->in, nb < h->in_total ? nb : h->in_total, h->in_total, ch);
+            if (rc) return rc;
+        }
+        size_t F_r, B_r;
+        long long out_limit;
+        if (h->flushed) {
+            F_r = fin.frames;
+            B_r = (fin.out_len + NAE_HOP - 1) / NAE_HOP;
+            out_limit = (long long)fin.out_len;
+        } else {
+            F_r = frames_available(pl, h->mid_total);
+            B_r = F_r >= 3 ? F_r - 3 : 0;
+            out_limit = (long long)1 << 60;
+        }
+        if (B_r > h->blocks_done) {
+            const int tile = ctx->pv_tile > 0 ? ctx->pv_tile : 64;
+            const size_t count = B_r - h->blocks_done;
+            int rc = nae_ws_reserve(ctx, &ctx->ws_phase, &ctx->ws_phase_bytes, nae_pv_phase_workspace_bytes(count, ch, 1, tile));
+            if (rc) return rc;
+            for (int i = 0; i < 2; i++)
+                if (!h->carry[i] && hipMalloc((void**)&h->carry[i], (size_t)ch * kPhasePad * sizeof(uint32_t)) != hipSuccess)
+                    return nae_fail(ctx, NAE_ERR_NOMEM, "hipMalloc(carry)");
+            nae_pv_segment seg{(long long)h->blocks_done, (long long)count, (long long)F_r, out_limit,
+                               h->blocks_done ? h->carry[h->carry_cur] : nullptr, h->carry[h->carry_cur ^ 1]};
+            const size_t produced_total = h->flushed ? fin.out_len : B_r * NAE_HOP;
+            rc = fifo_reserve_interleaved(ctx, h->out, h->out_total, produced_total, ch);
+            if (rc) return rc;
+            nae_sig src{h->mid.cur.p - (ptrdiff_t)h->mid.base * ch, 0, 1, (size_t)ch};
+            nae_sig dst{h->out.cur.p - (ptrdiff_t)h->out.base * ch, 0, 1, (size_t)ch};
+            rc = nae_launch_pv_phase(ctx, &pl, &src, h->mid_total, ch, 1, tile, static_cast<uint32_t*>(ctx->ws_phase), &seg);
+            if (rc) return rc;
+            rc = nae_launch_pv_synth(ctx, &pl, &src, h->mid_total, ch, 1, tile, static_cast<const uint32_t*>(ctx->ws_phase), &dst, &seg);
+            if (rc) return rc;
+            h->carry_cur ^= 1;
+            h->blocks_done = B_r;
+            h->out_total = produced_total;
+            const long long s_keep = frame_start_host(pl, (long long)B_r - 1);
+            rc = fifo_drop_interleaved(ctx, h->mid, s_keep > 0 ? (size_t)s_keep : 0, h->mid_total, ch);
+            if (rc) return rc;
+        }
+        return NAE_OK;
+    }
+    // ---- vocoder first: in -> [PV] -> mid (planar FIFO) -> [RS] -> out
     // ---- stage 1: phase vocoder over the hop blocks that became computable
     if (pl.pv_on) {
         size_t F_r, B_r;

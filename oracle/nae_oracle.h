@@ -82,8 +82,11 @@ typedef struct orc_stretch_plan {
     uint32_t r_q24[2];     /* round(2^24*256/d) for d = d0, d0+1                                      */
     uint64_t step_q32;     /* transposer step, Q32.32                                                 */
     size_t out_len;        /* final output length for the given input length                          */
-    size_t mid_len;        /* PV-stage samples the transposer needs (== out_len when rs_on == 0)      */
+    size_t mid_len;        /* length of the intermediate signal between the two stages:
+                              rs_first == 0: PV-stage samples the transposer needs (== out_len when rs_on == 0)
+                              rs_first == 1: transposer output = PV-stage input length                  */
     size_t frames;         /* PV frames to run                                                        */
+    int rs_first;          /* both stages on and rate_eff > 1: transposer FIRST (fewer samples reach the vocoder) */
 } orc_stretch_plan;
 int orc_stretch_plan_make(double rate, double pitch, size_t in_len, orc_stretch_plan* plan);
 /* full node on one interleaved buffer; dst holds plan.out_len*ch floats */

@@ -262,15 +262,23 @@ int orc_stretch_plan_make(double rate, double pitch, size_t in_len, orc_stretch_
     }
     pl->step_q32 = (uint64_t)llround(rho * 4294967296.0);
     pl->out_len = (size_t)floor((double)in_len / (tempo * rho) + 0.5);
-    if (pl->rs_on) {
+    pl->rs_first = pl->pv_on && pl->rs_on && rho > 1.0;
+    size_t pv_out;                                     /* samples the vocoder stage has to deliver */
+    if (pl->rs_first) {
+        pl->mid_len = (size_t)floor((double)in_len / rho + 0.5);   /* transposer output = vocoder input */
+        pv_out = pl->out_len;
+    } else if (pl->rs_on) {
         if (pl->out_len == 0) pl->mid_len = 0;
         else {
             const unsigned __int128 pos = (unsigned __int128)(pl->out_len - 1) * pl->step_q32;
             pl->mid_len = (size_t)(pos >> 32) + NAE_RS_TAPS / 2 + 1;
         }
-    } else
+        pv_out = pl->mid_len;
+    } else {
         pl->mid_len = pl->out_len;
-    pl->frames = pl->pv_on ? (pl->mid_len + NAE_FFT_N / 2 + NAE_HOP - 1) / NAE_HOP + 1 : 0;
+        pv_out = pl->out_len;
+    }
+    pl->frames = pl->pv_on ? (pv_out + NAE_FFT_N / 2 + NAE_HOP - 1) / NAE_HOP + 1 : 0;
     return 0;
 }
 
@@ -282,10 +290,9 @@ static inline int64_t frame_start(const orc_stretch_plan* pl, int64_t f)
 
 /* one channel of the phase-vocoder stage; v[0..mid_len) is overwritten.  qs_tap (optional) receives the
  * synthesis phases, stride `tap_stride` int32 per frame. */
-static void pv_channel(const float* src, size_t L, int ch, int c, const orc_stretch_plan* pl, float* v,
+static void pv_channel(const float* src, size_t L, int ch, int c, const orc_stretch_plan* pl, size_t M, float* v,
                        int32_t* qs_tap, size_t tap_stride)
 {
-    const size_t M = pl->mid_len;
     float xw[NAE_FFT_N], y[NAE_FFT_N];
     cf X[NAE_FFT_BINS], Y[NAE_FFT_BINS];
     uint32_t qa[NAE_FFT_BINS], qa_prev[NAE_FFT_BINS], qs[NAE_FFT_BINS];
@@ -335,10 +342,10 @@ static void pv_channel(const float* src, size_t L, int ch, int c, const orc_stre
         for (size_t m = 0; m < M; m++) v[m] *= NAE_OLA_GAIN;
 }
 
-static void rs_channel(const float* v, size_t M, size_t vstride, const orc_stretch_plan* pl, const float* tab,
+static void rs_channel(const float* v, size_t M, size_t vstride, const orc_stretch_plan* pl, size_t n_out, const float* tab,
                        float* dst, int ch, int c)
 {
-    for (size_t j = 0; j < pl->out_len; j++) {
+    for (size_t j = 0; j < n_out; j++) {
         const unsigned __int128 pos = (unsigned __int128)j * pl->step_q32;
         const int64_t idx = (int64_t)(pos >> 32);
         const uint32_t frac = (uint32_t)pos;
@@ -368,25 +375,44 @@ int orc_stretch_f32(const float* src, size_t L, int ch, double rate, double pitc
         return 0;
     }
     const float* tab = pl.rs_on ? orc_rs_table(pl.rate_eff) : NULL;
-    float* v = pl.pv_on ? (float*)malloc((pl.mid_len + 1) * sizeof(float)) : NULL;
+    const size_t vlen = pl.mid_len > pl.out_len ? pl.mid_len : pl.out_len;
+    float* v = pl.pv_on ? (float*)malloc((vlen + 1) * sizeof(float)) : NULL;
+    float* w = pl.rs_first ? (float*)malloc((pl.out_len + 1) * sizeof(float)) : NULL;
     for (int c = 0; c < ch; c++) {
-        if (pl.pv_on) {
-            pv_channel(src, L, ch, c, &pl, v, NULL, 0);
-            if (pl.rs_on) rs_channel(v, pl.mid_len, 1, &pl, tab, dst, ch, c);
+        if (pl.rs_first) {
+            /* transposer first: src -> v[0..mid_len), then the vocoder on v -> w[0..out_len) */
+            rs_channel(src + c, L, (size_t)ch, &pl, pl.mid_len, tab, v, 1, 0);
+            pv_channel(v, pl.mid_len, 1, 0, &pl, pl.out_len, w, NULL, 0);
+            for (size_t m = 0; m < pl.out_len; m++) dst[m * (size_t)ch + c] = w[m];
+        } else if (pl.pv_on) {
+            pv_channel(src, L, ch, c, &pl, pl.mid_len, v, NULL, 0);
+            if (pl.rs_on) rs_channel(v, pl.mid_len, 1, &pl, pl.out_len, tab, dst, ch, c);
             else
                 for (size_t m = 0; m < pl.out_len; m++) dst[m * (size_t)ch + c] = v[m];
         } else
-            rs_channel(src + c, L, (size_t)ch, &pl, tab, dst, ch, c);
+            rs_channel(src + c, L, (size_t)ch, &pl, pl.out_len, tab, dst, ch, c);
     }
     free(v);
+    free(w);
     return 0;
 }
 
+/* synthesis phases of the vocoder stage; with rs_first its input is the transposed signal */
 int orc_pv_synth_phase(const float* src, size_t L, int ch, const orc_stretch_plan* pl, int32_t* qs)
 {
     make_tables();
     if (!pl->pv_on) return -1;
+    if (pl->rs_first) {
+        const float* tab = orc_rs_table(pl->rate_eff);
+        float* v = (float*)malloc((pl->mid_len + 1) * sizeof(float));
+        for (int c = 0; c < ch; c++) {
+            rs_channel(src + c, L, (size_t)ch, pl, pl->mid_len, tab, v, 1, 0);
+            pv_channel(v, pl->mid_len, 1, 0, pl, pl->out_len, NULL, qs + (size_t)c * NAE_FFT_BINS, (size_t)ch * NAE_FFT_BINS);
+        }
+        free(v);
+        return 0;
+    }
     for (int c = 0; c < ch; c++)
-        pv_channel(src, L, ch, c, pl, NULL, qs + (size_t)c * NAE_FFT_BINS, (size_t)ch * NAE_FFT_BINS);
+        pv_channel(src, L, ch, c, pl, pl->mid_len, NULL, qs + (size_t)c * NAE_FFT_BINS, (size_t)ch * NAE_FFT_BINS);
     return 0;
 }

@@ -50,7 +50,7 @@ def test_stretch_plan_matches_oracle(nae, rate, pitch, L):
     pl = nae.Context.stretch_plan(rate, pitch, L)
     rc, ref = orc.plan(rate, pitch, L)
     assert rc == 0
-    for f in ("pv_on", "rs_on", "tempo_eff", "rate_eff", "ha_q24", "d0", "step_q32", "out_len", "mid_len", "frames"):
+    for f in ("pv_on", "rs_on", "tempo_eff", "rate_eff", "ha_q24", "d0", "step_q32", "out_len", "mid_len", "frames", "rs_first"):
         assert getattr(pl, f) == getattr(ref, f), f
     assert list(pl.r_q24) == list(ref.r_q24)
 
