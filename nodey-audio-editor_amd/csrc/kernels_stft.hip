@@ -309,6 +309,19 @@ __global__ __launch_bounds__(kThreads, kOcc) void pv_synth_kernel(SigViewD src, 
     // kOcc == 2 (256 VGPRs): software-pipelined input — frame f+1 is fetched while frame f is computed, so the
     // HBM/L2 latency of the only global read of the loop is never exposed
     constexpr bool kPrefetch = (kOcc <= 2);
+    // kOcc == 2: the per-lane window and split twiddles live in registers (32 VGPRs) instead of being re-read
+    // from LDS twice per frame; both FFT directions use the same natural index lane + 64 j
+    constexpr bool kRegTab = (kOcc <= 2);
+    cf win[8], tsp[8], tsp_nyq{0.0f, 0.0f};
+    if (kRegTab) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float2 w = *reinterpret_cast<const float2*>(L.hann + 2 * (lane + 64 * j));
+            win[j] = cf{w.x, w.y};
+            tsp[j] = L.t1024[lane + 64 * j];
+        }
+        tsp_nyq = L.t1024[512];
+    }
     cf nxt[8];
     const long long f_first = (b0 > 0 ? b0 - 1 : 0);
     if (kPrefetch && f_first < f_end) load_frame_raw<kUnit>(nxt, in, frame_start(p, f_first), lane);
@@ -319,14 +332,18 @@ __global__ __launch_bounds__(kThreads, kOcc) void pv_synth_kernel(SigViewD src, 
 #pragma unroll
             for (int j = 0; j < 8; j++) v[j] = nxt[j];
             if (f + 1 < f_end) load_frame_raw<kUnit>(nxt, in, frame_start(p, f + 1), lane);
-            apply_window(v, L.hann, lane);
+            if (kRegTab) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] = cf{v[j].x * win[j].x, v[j].y * win[j].y};
+            } else
+                apply_window(v, L.hann, lane);
         } else
             load_frame_windowed<kUnit>(v, in, s, L.hann, lane);
 #pragma unroll 1
         for (int half = 0; half < 2; half++) {
             fft512_fwd<(kOcc > 2)>(v, L.scratch, tw, lane);
             if (half == 0) {
-                const cf nyq = rfft_split(v, L.scratch, L.t1024, lane);
+                const cf nyq = kRegTab ? rfft_split_reg(v, L.scratch, tsp, tsp_nyq, lane) : rfft_split(v, L.scratch, L.t1024, lane);
                 uint32_t qa[9];
                 phases_of(v, nyq, qa);
                 if (f >= b0) {
@@ -369,7 +386,7 @@ __global__ __launch_bounds__(kThreads, kOcc) void pv_synth_kernel(SigViewD src, 
                 for (int r = 0; r < 8; r++) {
                     const int k = lane + 64 * r;
                     const cf Xk = L.scratch[k], Xm = L.scratch[512 - k];
-                    const cf T = L.t1024[k];
+                    const cf T = kRegTab ? tsp[r] : L.t1024[k];
                     const cf E{0.5f * (Xk.x + Xm.x), 0.5f * (Xk.y - Xm.y)};
                     const cf D{0.5f * (Xk.x - Xm.x), 0.5f * (Xk.y + Xm.y)};
                     const cf Q{__builtin_fmaf(T.x, D.x, T.y * D.y), __builtin_fmaf(T.x, D.y, -(T.y * D.x))};
@@ -382,7 +399,7 @@ __global__ __launch_bounds__(kThreads, kOcc) void pv_synth_kernel(SigViewD src, 
 #pragma unroll
                 for (int r = 0; r < 8; r++) {
                     const int n2 = 2 * (kl + 64 * r);
-                    const float2 w = *reinterpret_cast<const float2*>(L.hann + n2);
+                    const float2 w = kRegTab ? float2{win[r].x, win[r].y} : *reinterpret_cast<const float2*>(L.hann + n2);
                     const float y0 = v[r].x * (1.0f / 512.0f) * w.x;
                     const float y1 = -v[r].y * (1.0f / 512.0f) * w.y;
                     const int blk = (int)((f - 3 + (r >> 1)) & 3);

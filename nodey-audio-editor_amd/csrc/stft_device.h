@@ -155,6 +155,34 @@ __device__ __forceinline__ cf rfft_split(cf (&v)[8], cf* __restrict__ scratch, c
     return nyq;
 }
 
+// same split with the lane's 8 split twiddles T1024[lane + 64 r] and T1024[512] already in registers
+__device__ __forceinline__ cf rfft_split_reg(cf (&v)[8], cf* __restrict__ scratch, const cf (&tw)[8], cf tw_nyq, int lane)
+{
+#pragma unroll
+    for (int r = 0; r < 8; r++) scratch[lane + 64 * r] = v[r];
+    wave_lds_sync();
+    cf nyq;
+    {
+        const cf A = scratch[0];
+        const cf E = cf{0.5f * (A.x + A.x), 0.5f * (A.y - A.y)};
+        const cf O = cf{0.5f * (A.x - A.x), 0.5f * (A.y + A.y)};
+        const cf P = cmul_tw(O, tw_nyq);
+        nyq = cf{E.x + P.y, E.y - P.x};
+    }
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int k = lane + 64 * r;
+        const cf A = v[r];
+        const cf B = scratch[(512 - k) & 511];
+        const cf E = cf{0.5f * (A.x + B.x), 0.5f * (A.y - B.y)};
+        const cf O = cf{0.5f * (A.x - B.x), 0.5f * (A.y + B.y)};
+        const cf P = cmul_tw(O, tw[r]);
+        v[r] = cf{E.x + P.y, E.y - P.x};
+    }
+    wave_lds_sync();
+    return nyq;
+}
+
 // canonical atan2 in turns -> Q0.32
 __device__ __forceinline__ uint32_t atan2_q32(float im, float re)
 {
