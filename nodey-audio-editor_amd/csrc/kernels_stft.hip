@@ -88,40 +88,50 @@ __global__ __launch_bounds__(kThreads, 4) void spectrum_kernel(SigViewD src, lon
 }
 
 // interleaved-stereo fast path: one 16-byte load per lane fetches (L0 R0 L1 R1), so the frame is read once for both
-// channels and the window is applied once; requires a 16-byte aligned stream base and an even stream stride
+// channels and the window is applied once; requires a 16-byte aligned stream base and an even stream stride.
+// A wave walks kSpecChunk consecutive frames of one stream, so the table fill and the twiddle loads of the
+// workgroup are amortised over 8 x kSpecChunk frames.
+constexpr int kSpecChunk = 8;
 __global__ __launch_bounds__(kThreads, 4) void spectrum_stereo_kernel(const float* __restrict__ src, long long src_ss, long long T,
-                                                                     long long n_frames, long long n_items,
-                                                                     float* __restrict__ dst, long long dst_ss, Tables tb)
+                                                                     long long n_frames, long long chunks_per_stream,
+                                                                     long long n_items, float* __restrict__ dst,
+                                                                     long long dst_ss, Tables tb)
 {
     LdsLayout L = lds_setup<false>(tb);
     const int lane = threadIdx.x & 63;
     const long long item = (long long)blockIdx.x * kWaves + wave_id();
     if (item >= n_items) return;
-    const long long s = item / n_frames, f = item % n_frames;
+    const long long s = item / chunks_per_stream;
+    const long long f0 = (item % chunks_per_stream) * kSpecChunk;
+    long long f1 = f0 + kSpecChunk;
+    if (f1 > n_frames) f1 = n_frames;
     FftTw tw;
     load_fft_tw(tw, tb.w512, L.w64, lane);
-    const float* base = src + s * src_ss + 2 * (f * NAE_HOP);      // frames lie fully inside [0, T) by construction
     cf v0[8], v1[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const float4 t = *reinterpret_cast<const float4*>(base + 4 * (lane + 64 * j));
-        const float2 w = *reinterpret_cast<const float2*>(L.hann + 2 * (lane + 64 * j));
-        v0[j] = cf{t.x * w.x, t.z * w.y};
-        v1[j] = cf{t.y * w.x, t.w * w.y};
-    }
-    float* o = dst + s * dst_ss + (f * 2) * NAE_FFT_BINS;
 #pragma unroll 1
-    for (int c = 0; c < 2; c++) {
-        if (c == 1) {
+    for (long long f = f0; f < f1; f++) {
+        const float* base = src + s * src_ss + 2 * (f * NAE_HOP);  // frames lie fully inside [0, T) by construction
 #pragma unroll
-            for (int j = 0; j < 8; j++) v0[j] = v1[j];
+        for (int j = 0; j < 8; j++) {
+            const float4 t = *reinterpret_cast<const float4*>(base + 4 * (lane + 64 * j));
+            const float2 w = *reinterpret_cast<const float2*>(L.hann + 2 * (lane + 64 * j));
+            v0[j] = cf{t.x * w.x, t.z * w.y};
+            v1[j] = cf{t.y * w.x, t.w * w.y};
         }
-        fft512_fwd(v0, L.scratch, tw, lane);
-        const cf nyq = rfft_split(v0, L.scratch, L.t1024, lane);
+        float* o = dst + s * dst_ss + (f * 2) * NAE_FFT_BINS;
+#pragma unroll 1
+        for (int c = 0; c < 2; c++) {
+            if (c == 1) {
 #pragma unroll
-        for (int r = 0; r < 8; r++) o[lane + 64 * r] = __builtin_sqrtf(v0[r].x * v0[r].x + v0[r].y * v0[r].y);
-        if (lane == 0) o[512] = __builtin_sqrtf(nyq.x * nyq.x + nyq.y * nyq.y);
-        o += NAE_FFT_BINS;
+                for (int j = 0; j < 8; j++) v0[j] = v1[j];
+            }
+            fft512_fwd(v0, L.scratch, tw, lane);
+            const cf nyq = rfft_split(v0, L.scratch, L.t1024, lane);
+#pragma unroll
+            for (int r = 0; r < 8; r++) o[lane + 64 * r] = __builtin_sqrtf(v0[r].x * v0[r].x + v0[r].y * v0[r].y);
+            if (lane == 0) o[512] = __builtin_sqrtf(nyq.x * nyq.x + nyq.y * nyq.y);
+            o += NAE_FFT_BINS;
+        }
     }
 }
 
@@ -619,10 +629,13 @@ int nae_launch_spectrum(nae_ctx* ctx, const nae_sig* src, size_t T, int ch, size
     Tables tb{ctx->d_w512, ctx->d_t1024, ctx->d_hann};
     const bool stereo_fast = ch == 2 && src->chan_stride == 1 && src->frame_stride == 2 && src->stream_stride % 4 == 0 &&
                              (reinterpret_cast<uintptr_t>(src->base) & 15) == 0 && !getenv("NAE_SPEC_GENERIC");
-    if (stereo_fast)
-        NAE_KLAUNCH(ctx, "spectrum_kernel", spectrum_stereo_kernel, dim3(grid), dim3(kThreads), lds, ctx->stream,
-                    static_cast<const float*>(src->base), (long long)src->stream_stride, (long long)T, (long long)F, items, dst,
-                    (long long)dst_stream_stride, tb);
+    if (stereo_fast) {
+        const long long chunks = ((long long)F + kSpecChunk - 1) / kSpecChunk;
+        const long long citems = chunks * (long long)n_streams;
+        NAE_KLAUNCH(ctx, "spectrum_kernel", spectrum_stereo_kernel, dim3((unsigned)((citems + kWaves - 1) / kWaves)), dim3(kThreads),
+                    lds, ctx->stream, static_cast<const float*>(src->base), (long long)src->stream_stride, (long long)T,
+                    (long long)F, chunks, citems, dst, (long long)dst_stream_stride, tb);
+    }
     else if (src->frame_stride == 1)
         NAE_KLAUNCH(ctx, "spectrum_kernel", (spectrum_kernel<true>), dim3(grid), dim3(kThreads), lds, ctx->stream, to_view(src),
                     (long long)T, ch, (long long)F, items, dst, (long long)dst_stream_stride, tb);
