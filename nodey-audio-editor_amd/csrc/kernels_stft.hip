@@ -92,6 +92,11 @@ __global__ __launch_bounds__(kThreads, 4) void spectrum_kernel(SigViewD src, lon
 // A wave walks kSpecChunk consecutive frames of one stream, so the table fill and the twiddle loads of the
 // workgroup are amortised over 8 x kSpecChunk frames.
 constexpr int kSpecChunk = 8;
+#ifdef NAE_ABL_FAST_SQRT
+#define NAE_SPEC_SQRT(x) __builtin_amdgcn_sqrtf(x)
+#else
+#define NAE_SPEC_SQRT(x) __builtin_sqrtf(x)     // correctly rounded: spectrum output is bit-identical to the oracle
+#endif
 __global__ __launch_bounds__(kThreads, 4) void spectrum_stereo_kernel(const float* __restrict__ src, long long src_ss, long long T,
                                                                      long long n_frames, long long chunks_per_stream,
                                                                      long long n_items, float* __restrict__ dst,
@@ -128,8 +133,8 @@ __global__ __launch_bounds__(kThreads, 4) void spectrum_stereo_kernel(const floa
             fft512_fwd(v0, L.scratch, tw, lane);
             const cf nyq = rfft_split(v0, L.scratch, L.t1024, lane);
 #pragma unroll
-            for (int r = 0; r < 8; r++) o[lane + 64 * r] = __builtin_sqrtf(v0[r].x * v0[r].x + v0[r].y * v0[r].y);
-            if (lane == 0) o[512] = __builtin_sqrtf(nyq.x * nyq.x + nyq.y * nyq.y);
+            for (int r = 0; r < 8; r++) o[lane + 64 * r] = NAE_SPEC_SQRT(v0[r].x * v0[r].x + v0[r].y * v0[r].y);
+            if (lane == 0) o[512] = NAE_SPEC_SQRT(nyq.x * nyq.x + nyq.y * nyq.y);
             o += NAE_FFT_BINS;
         }
     }
