@@ -91,13 +91,19 @@ __global__ __launch_bounds__(kThreads, 4) void spectrum_kernel(SigViewD src, lon
 // channels and the window is applied once; requires a 16-byte aligned stream base and an even stream stride.
 // A wave walks kSpecChunk consecutive frames of one stream, so the table fill and the twiddle loads of the
 // workgroup are amortised over 8 x kSpecChunk frames.
-constexpr int kSpecChunk = 8;
+constexpr int kSpecChunk = 32;
 #ifdef NAE_ABL_FAST_SQRT
 #define NAE_SPEC_SQRT(x) __builtin_amdgcn_sqrtf(x)
 #else
 #define NAE_SPEC_SQRT(x) __builtin_sqrtf(x)     // correctly rounded: spectrum output is bit-identical to the oracle
 #endif
-__global__ __launch_bounds__(kThreads, 4) void spectrum_stereo_kernel(const float* __restrict__ src, long long src_ss, long long T,
+// Consecutive frames overlap by 768 of 1024 sample-frames = 6 of the 8 register rows of the FFT input layout
+// (pair index n = lane + 64 j, hop = 128 pairs = 2 rows), so the raw samples are kept in registers and each new
+// frame loads only its last 2 rows: HBM/L2 read traffic drops from ~3.4x to ~1.1x of the input.
+#ifndef NAE_SPEC_OCC
+#define NAE_SPEC_OCC 4
+#endif
+__global__ __launch_bounds__(kThreads, NAE_SPEC_OCC) void spectrum_stereo_kernel(const float* __restrict__ src, long long src_ss, long long T,
                                                                      long long n_frames, long long chunks_per_stream,
                                                                      long long n_items, float* __restrict__ dst,
                                                                      long long dst_ss, Tables tb)
@@ -112,16 +118,26 @@ __global__ __launch_bounds__(kThreads, 4) void spectrum_stereo_kernel(const floa
     if (f1 > n_frames) f1 = n_frames;
     FftTw tw;
     load_fft_tw(tw, tb.w512, L.w64, lane);
+    const float* sbase = src + s * src_ss + 4 * lane;              // frames lie fully inside [0, T) by construction
+    float4 raw[8];
+    {
+        const float* base = sbase + 2 * (f0 * NAE_HOP);
+#pragma unroll
+        for (int j = 0; j < 6; j++) raw[j + 2] = *reinterpret_cast<const float4*>(base + 256 * j);   // rows 0..5 of frame f0, pre-shifted
+    }
     cf v0[8], v1[8];
 #pragma unroll 1
     for (long long f = f0; f < f1; f++) {
-        const float* base = src + s * src_ss + 2 * (f * NAE_HOP);  // frames lie fully inside [0, T) by construction
+        const float* base = sbase + 2 * (f * NAE_HOP);
+#pragma unroll
+        for (int j = 0; j < 6; j++) raw[j] = raw[j + 2];
+        raw[6] = *reinterpret_cast<const float4*>(base + 256 * 6);
+        raw[7] = *reinterpret_cast<const float4*>(base + 256 * 7);
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            const float4 t = *reinterpret_cast<const float4*>(base + 4 * (lane + 64 * j));
             const float2 w = *reinterpret_cast<const float2*>(L.hann + 2 * (lane + 64 * j));
-            v0[j] = cf{t.x * w.x, t.z * w.y};
-            v1[j] = cf{t.y * w.x, t.w * w.y};
+            v0[j] = cf{raw[j].x * w.x, raw[j].z * w.y};
+            v1[j] = cf{raw[j].y * w.x, raw[j].w * w.y};
         }
         float* o = dst + s * dst_ss + (f * 2) * NAE_FFT_BINS;
 #pragma unroll 1
