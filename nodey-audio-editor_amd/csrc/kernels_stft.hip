@@ -466,6 +466,204 @@ __global__ __launch_bounds__(kThreads, kOcc) void pv_synth_kernel(SigViewD src, 
     }
 }
 
+// pass 3, software-pipelined form for long tiles at 2 waves per SIMD (256 VGPRs, one workgroup per CU):
+// iteration f runs the ANALYSIS FFT of frame f and the INVERSE FFT of frame f-1 in lockstep (fft512_fwd2), then
+// overlaps frame f's split / phase / rotation / c2r pre-twiddle with frame f-1's overlap-add and block store.
+// Same arithmetic, same summation order, 8 wave syncs per frame instead of 14.
+constexpr size_t kLdsPerWavePv2 = 2 * kScratchCf * sizeof(cf) + kRingFloats * sizeof(float);
+
+template <bool kUnit>
+__global__ __launch_bounds__(kThreads, 2) void pv_synth2_kernel(SigViewD src, PvParams p, long long n_items,
+                                                               const uint32_t* __restrict__ base_phase, OutViewD out,
+                                                               Tables tb)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
+    float* hann = reinterpret_cast<float*>(smem2);
+    cf* t1024 = reinterpret_cast<cf*>(smem2 + NAE_FFT_N * sizeof(float));
+    cf* w64 = t1024 + kT1024Pad;
+    for (int i = threadIdx.x; i < NAE_FFT_N; i += kThreads) hann[i] = tb.hann[i];
+    for (int i = threadIdx.x; i < NAE_FFT_BINS; i += kThreads) t1024[i] = tb.t1024[i];
+    if (threadIdx.x < 64) w64[threadIdx.x] = tb.w512[8 * (threadIdx.x >> 3) * (threadIdx.x & 7)];
+    __syncthreads();
+    unsigned char* wave_base = smem2 + kLdsTables + wave_id() * kLdsPerWavePv2;
+    cf* SA = reinterpret_cast<cf*>(wave_base);
+    cf* SS = SA + kScratchCf;
+    float* ring = reinterpret_cast<float*>(SS + kScratchCf);
+
+    const int lane = threadIdx.x & 63;
+    const long long item = (long long)blockIdx.x * kWaves + wave_id();
+    if (item >= n_items) return;
+    const long long sc = item / p.n_tiles;
+    const int tile = (int)(item % p.n_tiles);
+    const long long s_idx = sc / p.ch;
+    const int c = (int)(sc % p.ch);
+    ChanView in{src.base + s_idx * src.ss + c * src.cs, src.fs, p.in_len};
+    float* optr = out.base + s_idx * out.ss + c * out.cs;
+    const bool out_vec = (out.fs == 1) && ((reinterpret_cast<uintptr_t>(optr) & 15) == 0);
+    FftTw tw;
+    load_fft_tw(tw, tb.w512, w64, lane);
+
+    const long long b0 = p.f_origin + (long long)tile * p.tile;
+    long long b_end = b0 + p.tile;
+    if (b_end > p.f_stop) b_end = p.f_stop;
+    long long f_end = b_end + 3;
+    if (f_end > p.frames) f_end = p.frames;
+
+    uint32_t qs[9], qp[9];
+    {
+        const uint32_t* bp = base_phase + item * kT1024Pad;
+#pragma unroll
+        for (int r = 0; r < 8; r++) { qs[r] = bp[lane + 64 * r]; qp[r] = 0; }
+        qs[8] = bp[512];
+        qp[8] = 0;
+    }
+    // wsy = synthesis window with every constant of the tolerance path folded in: 1/512 (inverse FFT), 1/2 (the
+    // halves dropped from the c2r pre-twiddle below) and 2/3 (overlap-add gain); the sign of the odd sample undoes
+    // the conjugation of the inverse-by-forward FFT
+    cf win[8], wsy[8], tsp[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const float2 w = *reinterpret_cast<const float2*>(hann + 2 * (lane + 64 * j));
+        win[j] = cf{w.x, w.y};
+        wsy[j] = cf{w.x * (NAE_OLA_GAIN / 1024.0f), -w.y * (NAE_OLA_GAIN / 1024.0f)};
+        tsp[j] = t1024[lane + 64 * j];
+    }
+    const cf tsp_nyq = t1024[512];
+
+    // overlap-add of one synthesised frame (z = conj(time samples) * 512 in natural pair order) into the ring
+    auto ola = [&](const cf (&z)[8], long long fz) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int n2 = 2 * (lane + 64 * r);
+            const float y0 = z[r].x * wsy[r].x;
+            const float y1 = z[r].y * wsy[r].y;
+            const int blk = (int)((fz - 3 + (r >> 1)) & 3);
+            float2* slot = reinterpret_cast<float2*>(ring + blk * NAE_HOP + (n2 & (NAE_HOP - 1)));
+            if ((r >> 1) == 3) {
+                *slot = float2{y0, y1};
+            } else {
+                float2 a = *slot;
+                a.x += y0; a.y += y1;
+                *slot = a;
+            }
+        }
+    };
+    // store hop block fz-3 once frame fz has been added
+    auto emit = [&](long long fz) {
+        const long long be = fz - 3;                         // wave-uniform: block base and pointer stay scalar
+        if (be >= b0 && be < b_end && be * NAE_HOP < p.mid_len) {
+            const float4 a = *reinterpret_cast<const float4*>(ring + (int)(be & 3) * NAE_HOP + 4 * lane);
+            float* pb = optr + be * NAE_HOP * out.fs;
+            if ((be + 1) * NAE_HOP <= p.mid_len) {
+                if (out_vec) *reinterpret_cast<float4*>(pb + 4 * lane) = a;
+                else {
+                    const int fs = (int)out.fs, o = 4 * lane * fs;
+                    pb[o] = a.x; pb[o + fs] = a.y; pb[o + 2 * fs] = a.z; pb[o + 3 * fs] = a.w;
+                }
+            } else {
+                const int rem = (int)(p.mid_len - be * NAE_HOP), fs = (int)out.fs, o = 4 * lane * fs;
+                if (4 * lane + 0 < rem) pb[o] = a.x;
+                if (4 * lane + 1 < rem) pb[o + fs] = a.y;
+                if (4 * lane + 2 < rem) pb[o + 2 * fs] = a.z;
+                if (4 * lane + 3 < rem) pb[o + 3 * fs] = a.w;
+            }
+        }
+    };
+
+    cf va[8], zs[8], nxt[8];
+    bool have = false;          // zs holds the pre-twiddled spectrum of frame fz, waiting for its inverse FFT
+    long long fz = 0, s_prev = 0;
+    const long long f_first = (b0 > 0 ? b0 - 1 : 0);
+    if (f_first < f_end) load_frame_raw<kUnit>(nxt, in, frame_start(p, f_first), lane);
+#pragma unroll 1
+    for (long long f = f_first; f < f_end; f++) {
+        const long long s = frame_start(p, f);
+#pragma unroll
+        for (int j = 0; j < 8; j++) va[j] = cf{nxt[j].x * win[j].x, nxt[j].y * win[j].y};
+        if (f + 1 < f_end) load_frame_raw<kUnit>(nxt, in, frame_start(p, f + 1), lane);
+        if (have) fft512_fwd2(va, zs, SA, SS, tw, lane);
+        else fft512_fwd<false>(va, SA, tw, lane);
+        // ---- phase P1: split exchange (write Z) | overlap-add of frame fz
+#pragma unroll
+        for (int r = 0; r < 8; r++) SA[lane + 64 * r] = va[r];
+        if (have) ola(zs, fz);
+        wave_lds_sync();
+        // ---- phase P2: split (mirror read) -> X | store the completed block of frame fz
+        cf nyq;
+        {
+            const cf A = SA[0];
+            const cf E = cf{0.5f * (A.x + A.x), 0.5f * (A.y - A.y)};
+            const cf O = cf{0.5f * (A.x - A.x), 0.5f * (A.y + A.y)};
+            const cf P = cmul_tw(O, tsp_nyq);
+            nyq = cf{E.x + P.y, E.y - P.x};
+        }
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int k = lane + 64 * r;
+            const cf A = va[r];
+            const cf B = SA[(512 - k) & 511];
+            const cf E = cf{0.5f * (A.x + B.x), 0.5f * (A.y - B.y)};
+            const cf O = cf{0.5f * (A.x - B.x), 0.5f * (A.y + B.y)};
+            const cf P = cmul_tw(O, tsp[r]);
+            va[r] = cf{E.x + P.y, E.y - P.x};
+        }
+        if (have) emit(fz);
+        wave_lds_sync();
+        // ---- phase P3: phases, integer phase advance, rotation -> Y (natural order in SA)
+        uint32_t qa[9];
+        phases_of(va, nyq, qa);
+        if (f >= b0) {
+            if (f == 0) {
+#pragma unroll
+                for (int r = 0; r < 9; r++) qs[r] += qa[r];
+            } else {
+                const unsigned d = (unsigned)(s - s_prev);
+                const unsigned R = (d == (unsigned)p.d0) ? p.r_q24_0 : p.r_q24_1;
+                phase_inc(qa, qp, qs, lane, d, R);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 9; r++) qp[r] = qa[r];
+        s_prev = s;
+        have = (f >= b0);
+        if (have) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const float ph = (float)(int32_t)(qs[r] - qa[r]) * (1.0f / 4294967296.0f);
+                const float cs = __builtin_amdgcn_cosf(ph), sn = __builtin_amdgcn_sinf(ph);
+                cf y{__builtin_fmaf(va[r].x, cs, -(va[r].y * sn)), __builtin_fmaf(va[r].x, sn, va[r].y * cs)};
+                if (r == 0 && lane == 0) y.y = 0.0f;
+                SA[lane + 64 * r] = y;
+            }
+            if (lane == 0) {
+                const float ph = (float)(int32_t)(qs[8] - qa[8]) * (1.0f / 4294967296.0f);
+                const float cs = __builtin_amdgcn_cosf(ph), sn = __builtin_amdgcn_sinf(ph);
+                SA[512] = cf{__builtin_fmaf(nyq.x, cs, -(nyq.y * sn)), 0.0f};
+            }
+            wave_lds_sync();
+            // ---- phase P4: c2r pre-twiddle -> zs (input of the next iteration's inverse FFT)
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int k = lane + 64 * r;
+                const cf Xk = SA[k], Xm = SA[512 - k];
+                const cf T = tsp[r];
+                const cf E{Xk.x + Xm.x, Xk.y - Xm.y};       // 2E, 2D: the factor 1/2 lives in wsy
+                const cf D{Xk.x - Xm.x, Xk.y + Xm.y};
+                const cf Q{__builtin_fmaf(T.x, D.x, T.y * D.y), __builtin_fmaf(T.x, D.y, -(T.y * D.x))};
+                zs[r] = cf{E.x - Q.y, -(E.y + Q.x)};
+            }
+            fz = f;
+            wave_lds_sync();
+        }
+    }
+    if (have) {   // drain the last synthesised frame
+        fft512_fwd<false>(zs, SS, tw, lane);
+        ola(zs, fz);
+        wave_lds_sync();
+        emit(fz);
+    }
+}
+
 // rate transposer: out[j] = sum_i tab(phase)[i] * v[idx - 7 + i],  pos = j * step (Q32.32)
 struct RsParams { unsigned long long step_q32; long long src_len; long long out_len; int ch; long long j_begin; };
 
@@ -749,6 +947,16 @@ int nae_launch_pv_synth(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig*
     const bool low_occ = grid <= 256 || getenv("NAE_PV_LOWOCC");
 #define NAE_SYNTH(U, O) NAE_KLAUNCH(ctx, "pv_synth_kernel", (pv_synth_kernel<U, O>), dim3(grid), dim3(kThreads), lds, ctx->stream, \
                                     to_view(src), p, items, phase_ws, to_out(out), tb)
+    if (low_occ && !getenv("NAE_PV_NO_PIPELINE")) {
+        const size_t lds2 = kLdsTables + kWaves * kLdsPerWavePv2;
+        if (src->frame_stride == 1)
+            NAE_KLAUNCH(ctx, "pv_synth_kernel", (pv_synth2_kernel<true>), dim3(grid), dim3(kThreads), lds2, ctx->stream, to_view(src),
+                        p, items, phase_ws, to_out(out), tb);
+        else
+            NAE_KLAUNCH(ctx, "pv_synth_kernel", (pv_synth2_kernel<false>), dim3(grid), dim3(kThreads), lds2, ctx->stream, to_view(src),
+                        p, items, phase_ws, to_out(out), tb);
+        return nae_check(ctx, hipGetLastError(), "pv_synth2_kernel");
+    }
     if (src->frame_stride == 1) { if (low_occ) NAE_SYNTH(true, 2); else NAE_SYNTH(true, 4); }
     else { if (low_occ) NAE_SYNTH(false, 2); else NAE_SYNTH(false, 4); }
 #undef NAE_SYNTH

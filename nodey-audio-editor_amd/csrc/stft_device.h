@@ -123,6 +123,43 @@ __device__ __forceinline__ void fft512_fwd(cf (&v)[8], cf* __restrict__ scratch,
     dft8_fwd(v);
 }
 
+// two independent 512-point FFTs advanced in lockstep (same canonical arithmetic as fft512_fwd on each): the
+// instruction streams interleave, the LDS round trips overlap, and the pair needs 4 wave syncs instead of 8.
+__device__ __forceinline__ void fft512_fwd2(cf (&a)[8], cf (&b)[8], cf* __restrict__ sa, cf* __restrict__ sb, const FftTw& tw,
+                                            int lane)
+{
+    const int m = lane & 7, qq = lane >> 3;
+    dft8_fwd(a);
+    dft8_fwd(b);
+#pragma unroll
+    for (int q = 1; q < 8; q++) { a[q] = cmul_tw(a[q], tw.a[q - 1]); b[q] = cmul_tw(b[q], tw.a[q - 1]); }
+#pragma unroll
+    for (int q = 0; q < 8; q++) { const int o = (lane ^ (q << 3)) + 64 * q; sa[o] = a[q]; sb[o] = b[q]; }
+    wave_lds_sync();
+    {
+        const int base = m + 64 * qq;
+#pragma unroll
+        for (int j = 0; j < 8; j++) { const int o = base + ((j ^ qq) << 3); a[j] = sa[o]; b[j] = sb[o]; }
+    }
+    wave_lds_sync();
+    dft8_fwd(a);
+    dft8_fwd(b);
+#pragma unroll
+    for (int p = 1; p < 8; p++) { const cf w = tw.b[p]; a[p] = cmul_tw(a[p], w); b[p] = cmul_tw(b[p], w); }
+    {
+        const int base = (qq ^ ((m & 3) << 1)) | (m << 6);
+        const int ph = m >> 2;
+#pragma unroll
+        for (int p = 0; p < 8; p++) { const int o = base | ((p ^ ph) << 3); sa[o] = a[p]; sb[o] = b[p]; }
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int j = 0; j < 8; j++) { const int o = (lane ^ (((j & 3) << 1) | ((j >> 2) << 3))) + 64 * j; a[j] = sa[o]; b[j] = sb[o]; }
+    wave_lds_sync();
+    dft8_fwd(a);
+    dft8_fwd(b);
+}
+
 // canonical r2c split.  in: v[r] = Z[kl + 64 r].  out: v[r] = X[kl + 64 r]; returns X[512] (meaningful on lane 0).
 // Leaves Z in natural order in scratch[0..511].
 __device__ __forceinline__ cf rfft_split(cf (&v)[8], cf* __restrict__ scratch, const cf* __restrict__ t1024,
