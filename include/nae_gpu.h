@@ -189,6 +189,23 @@ int nae_stretch_receive(nae_stretch* h, float* dst, size_t max_frames, size_t* g
 int nae_stretch_receive_host(nae_stretch* h, float* dst_host, size_t max_frames, size_t* got);
 int nae_stretch_destroy(nae_stretch* h);
 
+/* ------------------------------------------------------------------ N2 input conversion (libswresample's role)
+ * replaces the SwrContext every mixer input runs through (audio-amix.cpp:212-240,263-282; audio-bimix.cpp:198-240,
+ * 259-294; utility/sw-resample.hpp:55-70): any supported format / mono|stereo / rate -> `out_rate` stereo f32.
+ * Identity inputs (same rate, stereo float) are a bit copy — the only case the reference pins.  Everything else is
+ * builder-defined and UNPINNED versus FFmpeg: sample scaling as K6, mono -> stereo as L = R = m/sqrt(2) (swr's default
+ * float rematrix), rate change by the K7 transposer (Kaiser-windowed sinc, 16 taps) with step in_rate/out_rate.
+ * convert() follows swr_convert(ctx, out, out_count, in, in_count): it consumes all n_in input frames, hands out at
+ * most max_out frames and keeps the rest buffered; planes == NULL drains (the flush idiom at audio-amix.cpp:281-282). */
+typedef struct nae_swr nae_swr;
+int nae_swr_create(nae_ctx* ctx, int in_fmt, int in_rate, int in_channels, int out_rate, nae_swr** h);
+int nae_swr_convert_host(nae_swr* h, const void* const* planes_host, size_t n_in, float* outL_host, float* outR_host,
+                         size_t max_out, size_t* n_out);
+size_t nae_swr_buffered(nae_swr* h);   /* output frames ready without more input */
+int nae_swr_destroy(nae_swr* h);
+/* mono -> interleaved stereo with gain (the rematrix step above), device pointers */
+int nae_mono_to_stereo_f32(nae_ctx* ctx, const float* mono, float* dst_interleaved, size_t S, float gain);
+
 /* ------------------------------------------------------------------ K8 FFT spectrum
  * no reference code (FFTW declared at xmake.lua:15,33, never called).  Spec: per channel, periodic-Hann
  * windowed 1024-point forward r2c DFT every 256 sample-frames, un-normalised (FFTW convention),

@@ -416,6 +416,18 @@ __global__ __launch_bounds__(kBlock) void to_f32_kernel(ConvPlanes pl, size_t S,
     }
 }
 
+// ------------------------------------------------------------------------------------------------ mono -> stereo
+__global__ __launch_bounds__(kBlock) void mono_to_stereo_kernel(const float* __restrict__ mono, float* __restrict__ dst,
+                                                               size_t S, float gain)
+{
+    const size_t tid = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = tid; i < S; i += stride) {
+        const float v = mono[i] * gain;
+        reinterpret_cast<float2*>(dst)[i] = float2{v, v};
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ synthetic input
 // counter-based splitmix64: element i of a stream is the (i+1)-th output of the generator seeded with `seed`
 __global__ __launch_bounds__(kBlock) void fill_uniform_kernel(float* __restrict__ dst, size_t n, size_t stream_stride,
@@ -486,6 +498,15 @@ int nae_fill_uniform_f32(nae_ctx* ctx, float* dst, size_t n_per_stream, size_t s
         if (rc) return rc;
     }
     return NAE_OK;
+}
+
+int nae_mono_to_stereo_f32(nae_ctx* ctx, const float* mono, float* dst, size_t S, float gain)
+{
+    if (!ctx || !mono || !dst) return NAE_ERR_INVALID;
+    if (S == 0) return NAE_OK;
+    if (reinterpret_cast<uintptr_t>(dst) & 7) return nae_fail(ctx, NAE_ERR_INVALID, "dst must be 8-byte aligned");
+    NAE_KLAUNCH(ctx, "mono_to_stereo_kernel", mono_to_stereo_kernel, dim3(grid_for(S)), dim3(kBlock), 0, ctx->stream, mono, dst, S, gain);
+    return nae_check(ctx, hipGetLastError(), "mono_to_stereo_kernel");
 }
 
 int nae_clamp_f32(nae_ctx* ctx, float* data, size_t n)

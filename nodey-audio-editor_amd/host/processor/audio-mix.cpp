@@ -21,48 +21,44 @@ namespace processor
 			};
 		}
 
-		// what swr_convert(.., out, S, in, n) does for 48 kHz stereo FLT/FLTP -> FLTP: append the frame's samples to
-		// an internal FIFO, hand out up to S of them (the caller's buffer was zero-filled by
-		// av_samples_alloc_array_and_samples: audio-amix.cpp:253-260), return how many were delivered
-		struct Swr_identity
+		// the SwrContext of the reference (audio-amix.cpp:212-240): any supported input -> 48 kHz stereo FLTP, as
+		// nae_swr (identity inputs are a bit copy; other rates / mono / integer formats are converted on the GPU,
+		// unpinned versus FFmpeg — include/nae_gpu.h "N2 input conversion")
+		struct Gpu_swr
 		{
-			std::deque<float> l, r;
+			nae_swr* h = nullptr;
 
-			static void require_supported(const Frame_data& f)
+			Gpu_swr() = default;
+			Gpu_swr(const Gpu_swr&) = delete;
+			Gpu_swr& operator=(const Gpu_swr&) = delete;
+			Gpu_swr(Gpu_swr&& o) noexcept : h(o.h) { o.h = nullptr; }
+			~Gpu_swr() { if (h) nae_swr_destroy(h); }
+
+			void open(const Frame_data& f)
 			{
-				const bool ok = f.sample_rate == std_sample_rate && f.ch_layout.nb_channels == 2
-					&& (f.format == AV_SAMPLE_FMT_FLT || f.format == AV_SAMPLE_FMT_FLTP);
-				if (!ok)
+				if (h) return;
+				const int rc = nae_swr_create(gpu::context(), f.format, f.sample_rate, f.ch_layout.nb_channels, std_sample_rate, &h);
+				if (rc != NAE_OK)
 					throw infra::Processor::Runtime_error(
 						"Failed to initialize software resampler",
-						"This build mixes 48 kHz stereo float streams only; other inputs need the rate/format converter (not built yet).",
-						infra::fmt("rate %d, channels %d, format %d", f.sample_rate, f.ch_layout.nb_channels, f.format)
+						"Cannot start the audio resampling process. Internal error may have occurred.",
+						infra::fmt("nae_swr_create: %s (rate %d, channels %d, format %d)", nae_last_error(gpu::context()),
+								   f.sample_rate, f.ch_layout.nb_channels, f.format)
 					);
 			}
-			void feed(const Frame_data& f)
+			// swr_convert(ctx, out, S, in, n): out_* are zero-filled by the caller; returns the frames delivered
+			int convert(const Frame_data* f, float* out_l, float* out_r, int S)
 			{
-				const int n = f.nb_samples;
-				if (f.format == AV_SAMPLE_FMT_FLT)
-				{
-					const float* p = reinterpret_cast<const float*>(f.data[0]);
-					for (int i = 0; i < n; i++) { l.push_back(p[2 * i]); r.push_back(p[2 * i + 1]); }
-				}
-				else
-				{
-					const float* a = reinterpret_cast<const float*>(f.data[0]);
-					const float* b = reinterpret_cast<const float*>(f.data[1]);
-					l.insert(l.end(), a, a + n);
-					r.insert(r.end(), b, b + n);
-				}
-			}
-			int drain(float* out_l, float* out_r, int S)  // out_* pre-zeroed
-			{
-				const int n = std::min<int>(S, (int)l.size());
-				std::copy(l.begin(), l.begin() + n, out_l);
-				std::copy(r.begin(), r.begin() + n, out_r);
-				l.erase(l.begin(), l.begin() + n);
-				r.erase(r.begin(), r.begin() + n);
-				return n;
+				if (!h) return 0;  // an input that ended before its first frame contributes silence
+				size_t got = 0;
+				const int rc = f ? nae_swr_convert_host(h, reinterpret_cast<const void* const*>(f->data), f->nb_samples, out_l, out_r, S, &got)
+								 : nae_swr_convert_host(h, nullptr, 0, out_l, out_r, S, &got);
+				if (rc != NAE_OK)
+					throw infra::Processor::Runtime_error(
+						"Software resampler failed", "Cannot convert audio sample rate or format. Internal error may have occurred.",
+						infra::fmt("nae_swr_convert_host returned error %d: %s", rc, nae_last_error(gpu::context()))
+					);
+				return (int)got;
 			}
 		};
 
@@ -171,8 +167,7 @@ namespace processor
 			input_items.emplace_back(try_item.value());
 		}
 		const auto output_item = infra::get_output_item<Audio_stream>(output, "output");
-		std::vector<Swr_identity> resamplers(input_num);
-		bool initial = false;
+		std::vector<Gpu_swr> resamplers(input_num);
 
 		nae_ctx* ctx = gpu::context();
 		gpu::Device_buffer d_in, d_out;
@@ -214,19 +209,14 @@ namespace processor
 			if (S == std::numeric_limits<int>::max()) S = 1152;  // :195
 			time_seconds += S / double(std_sample_rate);          // :199 (pts = END time of the frame)
 			auto new_frame = new_fltp_frame(S, time_seconds);
-			if (!initial)
-			{
-				for (int i = 0; i < input_num; i++)
-					if (frames[i]) Swr_identity::require_supported(*frames[i]);
-				initial = true;
-			}
-			// per-input "swr_convert" into zero-filled planes [i][2][S]
+			for (int i = 0; i < input_num; i++)
+				if (frames[i]) resamplers[i].open(*frames[i]);  // :206-243 (first frame of each input)
+			// per-input swr_convert into zero-filled planes [i][2][S]
 			const size_t plane = ((size_t)S + 3) / 4 * 4;
 			h_in.assign((size_t)input_num * 2 * plane, 0.0f);
 			for (int i = 0; i < input_num; i++)
 			{
-				if (frames[i]) resamplers[i].feed(*frames[i]);
-				const int got = resamplers[i].drain(&h_in[(2 * i) * plane], &h_in[(2 * i + 1) * plane], S);
+				const int got = resamplers[i].convert(frames[i], &h_in[(2 * i) * plane], &h_in[(2 * i + 1) * plane], S);
 				if (!frames[i] && got < S) count++;  // :290
 			}
 			float* di = static_cast<float*>(d_in.reserve(h_in.size() * sizeof(float)));
@@ -285,7 +275,7 @@ namespace processor
 	)
 	{
 		std::vector<std::shared_ptr<const Audio_frame>> buf_l, buf_r;
-		bool initial = false, left_eof = false, right_eof = false;
+		bool left_eof = false, right_eof = false;
 		double time_seconds = 0;
 		const auto input_item_optional_l = infra::get_input_item<Audio_stream>(input, "input_l");
 		const auto input_item_optional_r = infra::get_input_item<Audio_stream>(input, "input_r");
@@ -298,7 +288,7 @@ namespace processor
 			);
 		auto& input_item_l = input_item_optional_l.value().get();
 		auto& input_item_r = input_item_optional_r.value().get();
-		Swr_identity resampler_l, resampler_r;
+		Gpu_swr resampler_l, resampler_r;
 		nae_ctx* ctx = gpu::context();
 		gpu::Device_buffer d_in, d_out;
 		std::vector<float> h_in;
@@ -325,18 +315,12 @@ namespace processor
 			else S = 1152;
 			time_seconds += S / double(48000);
 			auto new_frame = new_fltp_frame(S, time_seconds);
-			if (!initial)
-			{
-				if (frame_l) Swr_identity::require_supported(*frame_l);
-				if (frame_r) Swr_identity::require_supported(*frame_r);
-				initial = true;
-			}
+			if (frame_l) resampler_l.open(*frame_l);
+			if (frame_r) resampler_r.open(*frame_r);
 			const size_t plane = ((size_t)S + 3) / 4 * 4;
 			h_in.assign(4 * plane, 0.0f);
-			if (frame_l) resampler_l.feed(*frame_l);
-			if (frame_r) resampler_r.feed(*frame_r);
-			const int convert_count_l = resampler_l.drain(&h_in[0], &h_in[plane], S);
-			const int convert_count_r = resampler_r.drain(&h_in[2 * plane], &h_in[3 * plane], S);
+			const int convert_count_l = resampler_l.convert(frame_l, &h_in[0], &h_in[plane], S);
+			const int convert_count_r = resampler_r.convert(frame_r, &h_in[2 * plane], &h_in[3 * plane], S);
 			float* di = static_cast<float*>(d_in.reserve(h_in.size() * sizeof(float)));
 			float* dout = static_cast<float*>(d_out.reserve(2 * plane * sizeof(float)));
 			gpu::check(nae_memcpy_h2d(ctx, di, h_in.data(), h_in.size() * sizeof(float)), "h2d");
@@ -403,7 +387,8 @@ namespace processor
 		gpu::Device_buffer d_a, d_b, d_out;
 
 		// one side's intake: "resample" (identity) + mono downmix on the GPU
-		auto intake = [&](Audio_stream& stream, bool& eof, bool& have, double& t, std::list<Frame>& frames)
+		Gpu_swr resampler_l, resampler_r;
+		auto intake = [&](Audio_stream& stream, bool& eof, bool& have, double& t, std::list<Frame>& frames, Gpu_swr& resampler)
 		{
 			if (eof) return;
 			const auto pop_result = stream.try_pop();
@@ -416,18 +401,17 @@ namespace processor
 			if (data.ch_layout.nb_channels != 2 && data.ch_layout.nb_channels != 1)
 				throw Runtime_error("Invalid audio channel layout", "Audio channel layout must be stereo or mono.",
 									infra::fmt("Invalid channel layout: %d", data.ch_layout.nb_channels));
-			Swr_identity::require_supported(data);
 			if (!have)
 			{
 				have = true;
+				resampler.open(data);                   // :563-588
 				t = data.pts * av_q2d(data.time_base);  // :589
 			}
-			const int n = data.nb_samples;
-			Swr_identity split;
-			split.feed(data);
-			std::vector<float> l(n), r(n);
-			split.drain(l.data(), r.data(), n);
+			// :594-604: resample into buffers of 2*nb_samples; the count delivered advances the clock
+			std::vector<float> l(2 * (size_t)data.nb_samples + 1, 0.0f), r(2 * (size_t)data.nb_samples + 1, 0.0f);
+			const int n = resampler.convert(&data, l.data(), r.data(), 2 * data.nb_samples);
 			t += double(n) / target_sample_rate;  // :618 — the frame is stamped with its END time
+			if (n == 0) return;
 			Frame new_frame;
 			new_frame.time_seconds = t;
 			new_frame.samples.resize(n);
@@ -470,8 +454,8 @@ namespace processor
 		while (!stop_token)
 		{
 			nae_fiber::this_fiber::yield();
-			intake(input_stream_l, eof_l, have_l, time_l, frames_l);
-			intake(input_stream_r, eof_r, have_r, time_r, frames_r);
+			intake(input_stream_l, eof_l, have_l, time_l, frames_l, resampler_l);
+			intake(input_stream_r, eof_r, have_r, time_r, frames_r, resampler_r);
 
 			if (frames_l.empty() && frames_r.empty() && eof_l && eof_r) break;
 			if (frames_r.empty() && eof_r)  // right ended: :732-752

@@ -3,9 +3,9 @@
 // src/processor/audio-bimix.cpp).  Same identifiers, pins and JSON keys, so saved projects keep loading
 // (src/infra/graph.cpp:399-408).
 //
-// Input envelope: the reference first converts every input to 48 kHz stereo FLTP with libswresample.  For 48 kHz
-// stereo FLT/FLTP that conversion is a pure deinterleave and is done here (K2); any other rate / layout / format
-// needs a real resampler (parity unpinned without FFmpeg) and raises Runtime_error.
+// Input envelope: the reference first converts every input to 48 kHz stereo FLTP with libswresample.  That role is
+// nae_swr here: 48 kHz stereo FLT/FLTP is a pure deinterleave (bit-exact, K2); other rates, mono and integer formats
+// are converted on the GPU with the builder's own filter (SURVEY.md §8f N2 — unpinned versus FFmpeg).
 #pragma once
 #include "audio-stream.hpp"
 

@@ -312,6 +312,66 @@ static void test_gpu_amix()
 	CHECK(same, "amix output bit-exact vs oracle, planar, pts = cumulative end time");
 }
 
+static void test_gpu_amix_converted_input()
+{
+	// input 1: 48 kHz stereo FLT (identity); input 2: 44.1 kHz MONO s16 -> converted on the GPU (N2)
+	const int S = 1152 * 6;
+	const int S2 = (int)(S * 44100.0 / 48000.0);
+	Runner r;
+	auto a = std::make_shared<Test_source>(), b = std::make_shared<Test_source>();
+	a->samples = uniform(S * 2, 15);
+	b->samples = uniform(S2, 16);
+	b->ch = 1;
+	b->format = AV_SAMPLE_FMT_S16;
+	b->sample_rate = 44100;
+	b->frame_size = 1024;
+	auto mix = std::make_shared<Audio_amix>();
+	Json::Value v;
+	v["input_num"] = 2;
+	v["volumes0"] = 0.5; v["locks0"] = false;
+	v["volumes1"] = 0.5; v["locks1"] = false;
+	mix->deserialize(v);
+	auto sink = std::make_shared<Test_sink>();
+	r.add_node(1, a); r.add_node(2, b); r.add_node(3, mix); r.add_node(4, sink);
+	r.add_link({1, "output", 3, "input_1"});
+	r.add_link({2, "output", 3, "input_2"});
+	r.add_link({3, "output", 4, "input"});
+	const bool ok = r.run();
+	CHECK(ok, "amix with a 44.1 kHz mono s16 input runs: " << r.get_processor_resources().at(3)->error_text);
+	if (!ok) return;
+	// expected second input: K6 (s16 / 32768) -> m/sqrt(2) on both channels -> transposer at 44100/48000
+	std::vector<int16_t> q(S2);
+	for (int i = 0; i < S2; i++) q[i] = (int16_t)std::lrintf(b->samples[i] * 32767.0f);
+	std::vector<float> f(S2), st(2 * (size_t)S2);
+	const void* pl[1] = {q.data()};
+	orc_to_f32_interleaved(ORC_FMT_S16, pl, S2, 1, f.data());
+	for (int i = 0; i < S2; i++) st[2 * i] = st[2 * i + 1] = f[i] * 0.70710678118654752440f;
+	const float rate = (float)(44100.0 / 48000.0);
+	orc_stretch_plan plan;
+	orc_stretch_plan_make((double)rate, 1.0, S2, &plan);
+	std::vector<float> conv(plan.out_len * 2);
+	orc_stretch_f32(st.data(), S2, 2, (double)rate, 1.0, conv.data());
+	// walk the mixer output: every sample = a*0.5 + b*0.5 with b from `conv` (zero once it is exhausted)
+	size_t pos = 0;
+	bool same = true;
+	for (auto& fr : sink->frames)
+	{
+		const Frame_data* d = fr->data();
+		for (int i = 0; i < d->nb_samples && same; i++, pos++)
+			for (int c = 0; c < 2 && same; c++)
+			{
+				const float xa = pos < (size_t)S ? a->samples[2 * pos + c] : 0.0f;
+				const float xb = pos < plan.out_len ? conv[2 * pos + c] : 0.0f;
+				float acc = 0.0f;
+				acc += xa * 0.5f;
+				acc += xb * 0.5f;
+				same = reinterpret_cast<const float*>(d->data[c])[i] == acc;
+			}
+	}
+	CHECK(pos >= (size_t)S, "mixed at least the longer input: " << pos);
+	CHECK(same, "amix output bit-exact vs oracle composition with a converted (44.1 kHz mono s16) input");
+}
+
 static void test_gpu_pitch_spectrum_fanout()
 {
 	const int S = 30000;
@@ -426,6 +486,7 @@ int main(int argc, char** argv)
 		test_error_capture();
 		test_gpu_volume();
 		test_gpu_amix();
+		test_gpu_amix_converted_input();
 		test_gpu_pitch_spectrum_fanout();
 		test_gpu_velocity_keep_pitch();
 		test_gpu_bimix_v2();

@@ -276,3 +276,55 @@ def test_fill_uniform_matches_oracle_generator(ctx):
     for s in range(ns):
         assert_bits(got[s], orc.fill_uniform(n, orc.stream_seed(5 + s, 1)), f"stream {s}")
     d.free()
+
+
+def test_n2_input_conversion(ctx, nae):
+    """nae_swr: identity input is a bit copy; mono s16 at 44.1 kHz -> 48 kHz stereo equals the oracle composition
+    K6 -> m/sqrt(2) -> transposer (builder-defined: unpinned versus libswresample)"""
+    import ctypes as C
+    lib = ctx.lib
+    # --- identity: 48 kHz stereo FLT in uneven chunks, swr_convert semantics (max_out smaller than what is buffered)
+    S = 5000
+    x = orc.fill_uniform(2 * S, 71)
+    h = C.c_void_p()
+    assert lib.nae_swr_create(ctx.h, nae.FMT_FLT, 48000, 2, 48000, C.byref(h)) == 0
+    outL, outR, got = [], [], C.c_size_t()
+    pos = 0
+    for n in (1152, 1152, 2000, 696):
+        chunk = np.ascontiguousarray(x[2 * pos: 2 * (pos + n)])
+        planes = (C.c_void_p * 1)(chunk.ctypes.data)
+        L, R = np.zeros(1000, np.float32), np.zeros(1000, np.float32)
+        assert lib.nae_swr_convert_host(h, planes, n, L.ctypes.data, R.ctypes.data, 1000, C.byref(got)) == 0
+        outL.append(L[: got.value].copy()); outR.append(R[: got.value].copy())
+        pos += n
+    while True:
+        L, R = np.zeros(1000, np.float32), np.zeros(1000, np.float32)
+        assert lib.nae_swr_convert_host(h, None, 0, L.ctypes.data, R.ctypes.data, 1000, C.byref(got)) == 0
+        if got.value == 0:
+            break
+        outL.append(L[: got.value].copy()); outR.append(R[: got.value].copy())
+    assert lib.nae_swr_destroy(h) == 0
+    assert_bits(np.concatenate(outL), x[0::2].copy(), "identity L")
+    assert_bits(np.concatenate(outR), x[1::2].copy(), "identity R")
+    # --- mono s16 @ 44.1 kHz
+    n = 22050
+    m = (orc.fill_uniform(n, 72) * 30000).astype(np.int16)
+    assert lib.nae_swr_create(ctx.h, nae.FMT_S16, 44100, 1, 48000, C.byref(h)) == 0
+    planes = (C.c_void_p * 1)(m.ctypes.data)
+    cap = 30000
+    L, R = np.zeros(cap, np.float32), np.zeros(cap, np.float32)
+    assert lib.nae_swr_convert_host(h, planes, n, L.ctypes.data, R.ctypes.data, cap, C.byref(got)) == 0
+    k1 = got.value
+    assert 0 < k1 < 24000
+    assert lib.nae_swr_convert_host(h, None, 0, L[k1:].ctypes.data, R[k1:].ctypes.data, cap - k1, C.byref(got)) == 0
+    total = k1 + got.value
+    assert lib.nae_swr_destroy(h) == 0
+    rc, f = orc.to_f32_interleaved(orc.FMT_S16, [m], n, 1)
+    st = (f * np.float32(0.70710678118654752440)).astype(np.float32)
+    rate = float(np.float32(44100.0 / 48000.0))
+    ref = orc.stretch(np.stack([st, st], 1).reshape(-1), 2, rate, 1.0)
+    assert total == ref.size // 2 == 24000
+    assert_bits(L[:total].copy(), ref[0::2].copy(), "resampled L")      # the transposer is bit-exact vs the oracle
+    assert_bits(R[:total].copy(), ref[1::2].copy(), "resampled R")
+    assert lib.nae_swr_create(ctx.h, 4, 48000, 2, 48000, C.byref(h)) == -2     # AV_SAMPLE_FMT_DBL
+    assert lib.nae_swr_create(ctx.h, nae.FMT_FLT, 48000, 6, 48000, C.byref(h)) == -1
