@@ -847,7 +847,7 @@ int nae_launch_spectrum(nae_ctx* ctx, const nae_sig* src, size_t T, int ch, size
     const size_t lds = kLdsTables + kWaves * kLdsPerWaveSpec;
     Tables tb{ctx->d_w512, ctx->d_t1024, ctx->d_hann};
     const bool stereo_fast = ch == 2 && src->chan_stride == 1 && src->frame_stride == 2 && src->stream_stride % 4 == 0 &&
-                             (reinterpret_cast<uintptr_t>(src->base) & 15) == 0 && !getenv("NAE_SPEC_GENERIC");
+                             (reinterpret_cast<uintptr_t>(src->base) & 15) == 0 && !ctx->dbg_spec_generic;
     if (stereo_fast) {
         const long long chunks = ((long long)F + kSpecChunk - 1) / kSpecChunk;
         const long long citems = chunks * (long long)n_streams;
@@ -944,10 +944,10 @@ int nae_launch_pv_synth(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig*
     const unsigned grid = (unsigned)((items + kWaves - 1) / kWaves);
     const size_t lds = kLdsTables + kWaves * kLdsPerWavePv;
     // few long tiles (<= one 512-thread workgroup per CU): the 2-waves-per-SIMD build has 256 VGPRs and no spills
-    const bool low_occ = grid <= 256 || getenv("NAE_PV_LOWOCC");
+    const bool low_occ = grid <= 256 || ctx->dbg_pv_lowocc;
 #define NAE_SYNTH(U, O) NAE_KLAUNCH(ctx, "pv_synth_kernel", (pv_synth_kernel<U, O>), dim3(grid), dim3(kThreads), lds, ctx->stream, \
                                     to_view(src), p, items, phase_ws, to_out(out), tb)
-    if (low_occ && !getenv("NAE_PV_NO_PIPELINE")) {
+    if (low_occ && !ctx->dbg_pv_no_pipeline) {
         const size_t lds2 = kLdsTables + kWaves * kLdsPerWavePv2;
         if (src->frame_stride == 1)
             NAE_KLAUNCH(ctx, "pv_synth_kernel", (pv_synth2_kernel<true>), dim3(grid), dim3(kThreads), lds2, ctx->stream, to_view(src),
@@ -973,7 +973,7 @@ int nae_launch_resample(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig*
     // tiled kernel while one tile's source span fits the staging buffer (rho <= 4), else the direct kernel
     const double rho = (double)pl->step_q32 / 4294967296.0;
     const long long span_need = (long long)(kRsOut * rho) + NAE_RS_TAPS + 8;
-    const bool tiled = span_need <= kRsMaxSpan && !getenv("NAE_RS_DIRECT");
+    const bool tiled = span_need <= kRsMaxSpan && !ctx->dbg_rs_direct;
     const int span_alloc = (int)((span_need + 3) & ~3ll);
     const size_t lds = ((NAE_RS_PHASES + 1) * kRsRow + (size_t)ch * span_alloc) * sizeof(float);
     const unsigned gx = tiled ? (unsigned)((count + kRsOut - 1) / kRsOut) : (unsigned)((count + 255) / 256);

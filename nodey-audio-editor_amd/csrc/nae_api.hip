@@ -69,7 +69,11 @@ int nae_ws_reserve(nae_ctx* ctx, void** p, size_t* have, size_t want)
     }
     size_t bytes = want + want / 8 + 4096;
     hipError_t e = hipMalloc(p, bytes);
-    if (e != hipSuccess) { *p = nullptr; return nae_check(ctx, e, "hipMalloc(workspace)") == NAE_ERR_HIP ? NAE_ERR_NOMEM : NAE_ERR_NOMEM; }
+    if (e != hipSuccess) {
+        *p = nullptr;
+        (void)nae_check(ctx, e, "hipMalloc(workspace)");
+        return NAE_ERR_NOMEM;
+    }
     *have = bytes;
     return NAE_OK;
 }
@@ -180,6 +184,10 @@ int nae_ctx_create(int device, nae_ctx** out)
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return NAE_ERR_HIP; }
     ctx->own_stream = true;
     if (const char* t = getenv("NAE_PV_TILE")) ctx->pv_tile = atoi(t) > 0 ? atoi(t) : 0;   // tuning knob (0 = automatic)
+    ctx->dbg_pv_lowocc = getenv("NAE_PV_LOWOCC") != nullptr;
+    ctx->dbg_pv_no_pipeline = getenv("NAE_PV_NO_PIPELINE") != nullptr;
+    ctx->dbg_rs_direct = getenv("NAE_RS_DIRECT") != nullptr;
+    ctx->dbg_spec_generic = getenv("NAE_SPEC_GENERIC") != nullptr;
     std::vector<nae::cf> w512, t1024;
     std::vector<float> hann;
     build_tables(w512, t1024, hann);

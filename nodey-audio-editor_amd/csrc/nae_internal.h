@@ -25,6 +25,11 @@ struct nae_ctx {
     float* d_rs_tab = nullptr; double rs_tab_rate = 0.0;
     std::vector<float> h_rs_tab;
     int pv_tile = 0;             // frames per phase-vocoder tile; 0 = choose per call (nae_pick_pv_tile)
+    // tuning / A-B switches, read once from the environment at context creation (tools/ab.sh)
+    bool dbg_pv_lowocc = false;      // NAE_PV_LOWOCC: force the 2-waves-per-SIMD synth build
+    bool dbg_pv_no_pipeline = false; // NAE_PV_NO_PIPELINE: use the non-pipelined synth kernel for long tiles
+    bool dbg_rs_direct = false;      // NAE_RS_DIRECT: direct (unstaged) transposer kernel
+    bool dbg_spec_generic = false;   // NAE_SPEC_GENERIC: skip the interleaved-stereo spectrum fast path
     // optional per-kernel timing (hipEvent pairs on the ctx stream), used by bench.py for the roofline line
     bool prof_on = false;
     struct ProfSlot { const char* name; double total_ms; uint64_t launches; };

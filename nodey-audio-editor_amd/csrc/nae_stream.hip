@@ -267,7 +267,6 @@ int stretch_process(nae_stretch* h)
                 dst = nae_sig{h->out.cur.p - (ptrdiff_t)h->out.base * ch, 0, 1, (size_t)ch};
                 if (h->flushed) seg.mid_limit = (long long)fin.out_len;
             }
-            if (getenv("NAE_TRACE")) fprintf(stderr, "[pv] blocks %zu -> %zu  F_r %zu in_total %zu in.base %zu produced_total %zu mid.base %zu cap %zu\n", h->blocks_done, B_r, F_r, h->in_total, h->in.base, produced_total, h->mid.base, h->mid_cap);
             rc = nae_launch_pv_phase(ctx, &pl, &src, h->in_total, ch, 1, tile, static_cast<uint32_t*>(ctx->ws_phase), &seg);
             if (rc) return rc;
             rc = nae_launch_pv_synth(ctx, &pl, &src, h->in_total, ch, 1, tile, static_cast<const uint32_t*>(ctx->ws_phase), &dst, &seg);
@@ -301,7 +300,6 @@ int stretch_process(nae_stretch* h)
                                    : nae_sig{h->in.cur.p - (ptrdiff_t)h->in.base * ch, 0, 1, (size_t)ch};
             nae_sig dst{h->out.cur.p - (ptrdiff_t)h->out.base * ch, 0, 1, (size_t)ch};
             const size_t src_len = h->flushed ? (pl.pv_on ? fin.mid_len : h->in_total) : src_avail;
-            if (getenv("NAE_TRACE")) fprintf(stderr, "[rs] out_total %zu -> %zu  src_avail %zu src_len %zu mid.base %zu in.base %zu\n", h->out_total, J_r, src_avail, src_len, h->mid.base, h->in.base);
             rc = nae_launch_resample(ctx, &pl, &src, src_len, ch, 1, ctx->d_rs_tab, &dst, h->out_total, J_r);
             if (rc) return rc;
             h->out_total = J_r;

@@ -328,3 +328,45 @@ def test_n2_input_conversion(ctx, nae):
     assert_bits(R[:total].copy(), ref[1::2].copy(), "resampled R")
     assert lib.nae_swr_create(ctx.h, 4, 48000, 2, 48000, C.byref(h)) == -2     # AV_SAMPLE_FMT_DBL
     assert lib.nae_swr_create(ctx.h, nae.FMT_FLT, 48000, 6, 48000, C.byref(h)) == -1
+
+
+def test_many_streams_and_empty_calls(ctx, nae):
+    """more streams than blockIdx.y can index in one launch (65535), and zero-sized calls"""
+    n, S = 70001, 8
+    x = orc.fill_uniform(n * S * 2, 81)
+    d_x, d_pl, d_y = ctx.array(x), ctx.empty(x.size), ctx.empty(x.size)
+    ctx.copy_sig(nae.Sig.interleaved(d_x.ptr, S, 2), nae.Sig.planar(d_pl.ptr, S, 2), S, 2, n)
+    pl = d_pl.download().reshape(n, 2, S)
+    assert np.array_equal(pl[:, 0, :], x.reshape(n, S, 2)[:, :, 0]) and np.array_equal(pl[:, 1, :], x.reshape(n, S, 2)[:, :, 1])
+    ctx.amix_sig([nae.Sig.interleaved(d_x.ptr, S, 2), nae.Sig.interleaved(d_x.ptr, S, 2)], [0.25, 0.5], nae.Sig.planar(d_y.ptr, S, 2), S, n)
+    y = d_y.download().reshape(n, 2, S)
+    ref = ((np.float32(0) + x * np.float32(0.25)).astype(np.float32) + (x * np.float32(0.5)).astype(np.float32)).astype(np.float32)
+    assert np.array_equal(y[:, 0, :], ref.reshape(n, S, 2)[:, :, 0]) and np.array_equal(y[:, 1, :], ref.reshape(n, S, 2)[:, :, 1])
+    ctx.fill_uniform(d_y.ptr, 4, 4, n, 3, 2)
+    f = d_y.download()[: 4 * n].reshape(n, 4)
+    for s in (0, 65534, 65535, 65536, 70000):
+        assert_bits(f[s], orc.fill_uniform(4, orc.stream_seed(3 + s, 2)), f"stream {s}")
+    # zero-sized work is a no-op, not an error
+    ctx.copy_sig(nae.Sig.interleaved(d_x.ptr, 0, 2), nae.Sig.planar(d_pl.ptr, 0, 2), 0, 2, 5)
+    ctx.amix_sig([nae.Sig.interleaved(d_x.ptr, S, 2)], [1.0], nae.Sig.planar(d_y.ptr, S, 2), S, 0)
+    ctx.gain(np.float32, [d_x.ptr], [d_y.ptr], 0, 0.5)
+    ctx.spectrum_block(nae.Sig.interleaved(d_x.ptr, 100, 2), 100, 2, 3, d_y.ptr, 0)
+    ctx.stretch_block(1.0, 2 ** (3 / 12), nae.Sig.interleaved(d_x.ptr, 0, 2), 0, 2, 4, nae.Sig.interleaved(d_y.ptr, 0, 2))
+    ctx.sync()
+    for a in (d_x, d_pl, d_y):
+        a.free()
+
+
+def test_non_finite_input_does_not_fault(ctx, nae):
+    """NaN / Inf samples flow through every node without a GPU fault (values are outside the bit-exact guarantee)"""
+    S = 6000
+    x = orc.fill_uniform(2 * S, 83)
+    x[100] = np.nan; x[2001] = np.inf; x[4002] = -np.inf
+    d_x, d_y = ctx.array(x), ctx.empty(4 * S)
+    p = 2 ** (3 / 12)
+    pl = ctx.stretch_plan(1.0, p, S)
+    ctx.stretch_block(1.0, p, nae.Sig.interleaved(d_x.ptr, S, 2), S, 2, 1, nae.Sig.interleaved(d_y.ptr, pl.out_len, 2))
+    ctx.spectrum_block(nae.Sig.interleaved(d_x.ptr, S, 2), S, 2, 1, d_y.ptr, 0)
+    ctx.sync()
+    assert ctx.poll() == 1
+    d_x.free(); d_y.free()
