@@ -286,8 +286,21 @@ __global__ void pv_scan_kernel(uint32_t* __restrict__ sums, long long n_sc, int 
     if (sc >= n_sc || k >= NAE_FFT_BINS) return;
     uint32_t* p = sums + sc * n_tiles * (long long)kT1024Pad + k;
     uint32_t run = carry_in ? carry_in[sc * kT1024Pad + k] : 0u;
-    for (int j = 0; j < n_tiles; j++) {
-        const uint32_t v = (last_unwritten && j == n_tiles - 1) ? 0u : p[(long long)j * kT1024Pad];
+    const int n_read = last_unwritten ? n_tiles - 1 : n_tiles;   // the last tile's sum may not exist
+    int j = 0;
+    // the loads do not depend on the running sum: fetch 8 tiles ahead, then prefix them
+    for (; j + 8 <= n_read; j += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = p[(long long)(j + u) * kT1024Pad];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            p[(long long)(j + u) * kT1024Pad] = run;
+            run += v[u];
+        }
+    }
+    for (; j < n_tiles; j++) {
+        const uint32_t v = (j < n_read) ? p[(long long)j * kT1024Pad] : 0u;
         p[(long long)j * kT1024Pad] = run;
         run += v;
     }
