@@ -216,7 +216,8 @@ __device__ __forceinline__ void phase_inc(const uint32_t (&qa)[9], const uint32_
         const uint32_t e = ((k * d) & (NAE_FFT_N - 1)) << 22;
         const int32_t dw = (int32_t)(qa[r] - qp[r] - e);
         const uint32_t adv = ((k * NAE_HOP) & (NAE_FFT_N - 1)) << 22;
-        const long long scaled = ((long long)dw * (long long)R + (1ll << (NAE_R_FRAC_BITS - 1))) >> NAE_R_FRAC_BITS;
+        // R <= 2^26 (d >= 64), so it is a positive int32: one signed 32x32->64 multiply-add (v_mad_i64_i32)
+        const long long scaled = ((long long)dw * (long long)(int32_t)R + (1ll << (NAE_R_FRAC_BITS - 1))) >> NAE_R_FRAC_BITS;
         acc[r] += adv + (uint32_t)scaled;
     }
 }
