@@ -189,6 +189,42 @@ int nae_stretch_receive(nae_stretch* h, float* dst, size_t max_frames, size_t* g
 int nae_stretch_receive_host(nae_stretch* h, float* dst_host, size_t max_frames, size_t* got);
 int nae_stretch_destroy(nae_stretch* h);
 
+/* ------------------------------------------------------------------ K7 option A (N1): SoundTouch-shaped time-domain chain
+ * The same call sites as above (audio-velocity.cpp:369-385 create + setSampleRate/setChannels/setRate/setPitch,
+ * :403 putSamples, :399 numSamples, :298 receiveSamples, :427 flush), with SoundTouch 2.3.2's own algorithm instead
+ * of the phase vocoder: WSOLA stretcher (8 ms overlap, automatic 40-90 ms sequence / 15-20 ms seek window,
+ * exhaustive normalised cross-correlation search), 64-tap anti-alias FIR and 4-point cubic transposer, in the
+ * library's stage order (stretcher first for rate > 1, transposer first otherwise) and with its flush rule
+ * (zero blocks of 128 frames until round(in / rate) frames exist, at most 200 of them).  The library is not in the
+ * reference tree, so the algorithm is restated and parity versus SoundTouch itself is UNPINNED;
+ * the GPU result is bit-exact versus oracle/orc_wsola.c.  `rate`, `pitch` as for nae_stretch_create. */
+typedef struct nae_wsola nae_wsola;
+typedef struct nae_wsola_plan {
+    int sample_rate, channels;
+    double rate_eff, tempo_eff;      /* rate*pitch, 1/pitch */
+    int order;                       /* 0: stretcher, filter, transposer (rate_eff > 1)   1: filter, transposer,
+                                        stretcher (== 1)   2: transposer, filter, stretcher (< 1) */
+    int overlap_len, seq_len, seek_len, sample_req;
+    double nominal_skip;
+    size_t in_len, flush_zeros;      /* zeros the flush rule appends */
+    size_t n_seq;                    /* WSOLA sequences */
+    size_t td_out_len, aa_out_len, cu_out_len;
+    size_t out_len;                  /* frames delivered for in_len frames of input */
+} nae_wsola_plan;
+int nae_wsola_plan_make(int sample_rate, int channels, double rate, double pitch, size_t in_len, nae_wsola_plan* plan);
+/* block form: n_streams independent signals of in_len frames; dst receives plan.out_len frames per stream (one put,
+ * flush, receive-all).  offsets_dbg (device, optional): [n_streams][n_seq - 1] chosen overlap offsets. */
+int nae_wsola_block_f32(nae_ctx* ctx, int sample_rate, double rate, double pitch, const nae_sig* src, size_t in_len, int ch,
+                        size_t n_streams, const nae_sig* dst, int32_t* offsets_dbg);
+int nae_wsola_create(nae_ctx* ctx, int sample_rate, int channels, double rate, double pitch, nae_wsola** h);
+int nae_wsola_put(nae_wsola* h, const float* interleaved, size_t S);
+int nae_wsola_put_host(nae_wsola* h, const float* interleaved_host, size_t S);
+int nae_wsola_flush(nae_wsola* h);
+size_t nae_wsola_available(const nae_wsola* h);
+int nae_wsola_receive(nae_wsola* h, float* dst, size_t max_frames, size_t* got);
+int nae_wsola_receive_host(nae_wsola* h, float* dst_host, size_t max_frames, size_t* got);
+int nae_wsola_destroy(nae_wsola* h);
+
 /* ------------------------------------------------------------------ N2 input conversion (libswresample's role)
  * replaces the SwrContext every mixer input runs through (audio-amix.cpp:212-240,263-282; audio-bimix.cpp:198-240,
  * 259-294; utility/sw-resample.hpp:55-70): any supported format / mono|stereo / rate -> `out_rate` stereo f32.

@@ -9,6 +9,6 @@ The directory name carries a hyphen (it mirrors the upstream repository name), s
 ``naeload.load()`` at the repo root, which registers it as ``nodey_audio_editor_amd``.
 """
 from .binding import (  # noqa: F401
-    NaeError, Context, DeviceArray, Sig, StretchPlan, Graph4, lib_path, load_library, build_library,
+    NaeError, Context, DeviceArray, Sig, StretchPlan, WsolaPlan, Graph4, lib_path, load_library, build_library,
     FMT_S16, FMT_S32, FMT_FLT, FMT_S16P, FMT_S32P, FMT_FLTP, FFT_N, HOP, BINS, EXPORTED_SYMBOLS,
 )

@@ -28,6 +28,8 @@ EXPORTED_SYMBOLS = [
     "nae_swr_create", "nae_swr_convert_host", "nae_swr_buffered", "nae_swr_destroy", "nae_mono_to_stereo_f32",
     "nae_spectrum_frames", "nae_spectrum_block_f32", "nae_spectrum_create", "nae_spectrum_put",
     "nae_spectrum_available", "nae_spectrum_receive", "nae_spectrum_destroy", "nae_graph4_run",
+    "nae_wsola_plan_make", "nae_wsola_block_f32", "nae_wsola_create", "nae_wsola_put", "nae_wsola_put_host",
+    "nae_wsola_flush", "nae_wsola_available", "nae_wsola_receive", "nae_wsola_receive_host", "nae_wsola_destroy",
 ]
 
 
@@ -72,6 +74,14 @@ class StretchPlan(C.Structure):
     _fields_ = [("pv_on", C.c_int), ("rs_on", C.c_int), ("tempo_eff", C.c_double), ("rate_eff", C.c_double),
                 ("ha_q24", C.c_int64), ("d0", C.c_int32), ("r_q24", C.c_uint32 * 2), ("step_q32", C.c_uint64),
                 ("out_len", C.c_size_t), ("mid_len", C.c_size_t), ("frames", C.c_size_t), ("rs_first", C.c_int)]
+
+
+class WsolaPlan(C.Structure):
+    _fields_ = [("sample_rate", C.c_int), ("channels", C.c_int), ("rate_eff", C.c_double), ("tempo_eff", C.c_double),
+                ("order", C.c_int), ("overlap_len", C.c_int), ("seq_len", C.c_int), ("seek_len", C.c_int),
+                ("sample_req", C.c_int), ("nominal_skip", C.c_double), ("in_len", C.c_size_t),
+                ("flush_zeros", C.c_size_t), ("n_seq", C.c_size_t), ("td_out_len", C.c_size_t),
+                ("aa_out_len", C.c_size_t), ("cu_out_len", C.c_size_t), ("out_len", C.c_size_t)]
 
 
 class Graph4(C.Structure):
@@ -133,6 +143,12 @@ def load_library() -> C.CDLL:
         "nae_spectrum_create": (i, [vp, i, i, i, P(vp)]), "nae_spectrum_put": (i, [vp, vp, sz]),
         "nae_spectrum_available": (sz, [vp]), "nae_spectrum_receive": (i, [vp, vp, sz, P(sz)]),
         "nae_spectrum_destroy": (i, [vp]), "nae_graph4_run": (i, [vp, P(Graph4)]),
+        "nae_wsola_plan_make": (i, [i, i, d, d, sz, P(WsolaPlan)]),
+        "nae_wsola_block_f32": (i, [vp, i, d, d, P(Sig), sz, i, sz, P(Sig), vp]),
+        "nae_wsola_create": (i, [vp, i, i, d, d, P(vp)]), "nae_wsola_put": (i, [vp, vp, sz]),
+        "nae_wsola_put_host": (i, [vp, vp, sz]), "nae_wsola_flush": (i, [vp]), "nae_wsola_available": (sz, [vp]),
+        "nae_wsola_receive": (i, [vp, vp, sz, P(sz)]), "nae_wsola_receive_host": (i, [vp, vp, sz, P(sz)]),
+        "nae_wsola_destroy": (i, [vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)
@@ -352,6 +368,20 @@ class Context:
         self._ck(self.lib.nae_debug_pv_tile_phase(self.h, rate, pitch, C.byref(src), in_len, ch, n_streams,
                                                   out.ctypes.data, cap, C.byref(nt), C.byref(tf)))
         return out[: n_streams * ch * nt.value * BINS].reshape(n_streams, ch, nt.value, BINS), tf.value
+
+    # -- K7 option A: SoundTouch-shaped WSOLA chain
+    @staticmethod
+    def wsola_plan(sample_rate: int, ch: int, rate: float, pitch: float, in_len: int) -> WsolaPlan:
+        pl = WsolaPlan()
+        rc = load_library().nae_wsola_plan_make(sample_rate, ch, rate, pitch, in_len, C.byref(pl))
+        if rc:
+            raise NaeError(f"nae_wsola_plan_make({sample_rate}, {ch}, {rate}, {pitch}) failed: {rc}")
+        return pl
+
+    def wsola_block(self, sample_rate: int, rate: float, pitch: float, src: Sig, in_len: int, ch: int, n_streams: int,
+                    dst: Sig, offsets_dbg: int = 0):
+        self._ck(self.lib.nae_wsola_block_f32(self.h, sample_rate, rate, pitch, C.byref(src), in_len, ch, n_streams,
+                                              C.byref(dst), offsets_dbg))
 
     # -- K8
     def spectrum_frames(self, T: int) -> int:

@@ -1,0 +1,418 @@
+// kernels_wsola.hip — K7 option A: the SoundTouch-shaped time-domain chain on gfx950.
+//
+// Replaces what soundtouch::SoundTouch does between putSamples and receiveSamples for
+// /root/reference/src/processor/audio-velocity.cpp:369-428 (library absent: algorithm restated).
+// Three kernels, all bit-exact against oracle/orc_wsola.c (this file is built with -ffp-contract=off):
+//
+//   st_td_kernel   WSOLA stretcher.  One 256-thread workgroup walks one stream's sequences in order (the chosen
+//                  offset of sequence k decides the tail that sequence k+1 is matched against, so sequences of a
+//                  stream are serial; streams are parallel).  Per sequence the seek window is staged in LDS and
+//                  every thread scores 4 candidate offsets at once: candidates 2 frames (16 B) apart see the same
+//                  4-float groups one step later, so one LDS read of the window feeds 4 candidates and the stored
+//                  tail is read once per step through a 4-deep register window.  The window is stored transposed
+//                  (row = unit mod R) so that a half-wave reads consecutive LDS words: conflict-free.
+//                  VALU-bound: 13 flop per candidate per 4 floats (4 mul + 4 add correlation, 1 mul + 4 add norm).
+//   st_aa_kernel   64-tap FIR, 4 consecutive outputs per thread from a 67-frame register window, even and odd taps
+//                  summed separately (the SSE stereo order); mono accumulates in double.
+//   st_cu_kernel   4-point cubic read at host-tabulated positions (the position accumulator is a sequential
+//                  double recurrence that does not depend on the audio: st_chain.h).
+#include "st_chain.h"
+
+namespace nae {
+
+constexpr int kTdThreads = 256;
+
+__device__ __forceinline__ float ld_frame(const StView& v, const float* sbase, long long a, int k)
+{
+    return (a < v.valid_end) ? sbase[k * v.cs + (a - v.origin) * v.fs] : 0.0f;
+}
+
+struct TdParams {
+    int ovl, seekl, body, first_skip;
+    double nominal_skip;
+    long long ip0, op0, nseq, out_limit;
+    double skip0;
+    int begin0;
+    int S;          // LDS row stride of the window, in units
+};
+
+// geometry of the transposed window: CH = 2: unit = one frame (8 B), 2 units per 4-float group, 8 rows (+1 copy)
+//                                     CH = 1: unit = one sample,      4 units per group,        16 rows (+3 copies)
+template <int CH> struct TdGeo {
+    static constexpr int P = 4 / CH;          // units per group = spacing of the candidates one thread owns
+    static constexpr int R = 4 * P;           // rows
+    static constexpr int ROWS = R + P - 1;    // with the wrapped copies
+    static constexpr int LANES = 64 / P;      // lanes that share one p
+};
+
+struct Best {
+    double v;
+    int i;
+};
+__device__ __forceinline__ Best better(Best a, Best b)
+{
+    return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
+}
+
+template <int CH>
+__global__ __launch_bounds__(kTdThreads) void st_td_kernel(StView in, TdParams p, StOut out, float* __restrict__ mid_state,
+                                                          int32_t* __restrict__ offs_dbg, long long offs_stride)
+{
+    using G = TdGeo<CH>;
+    extern __shared__ __attribute__((aligned(16))) float td_smem[];
+    const int ng = p.ovl * CH / 4;                       // 4-float groups per candidate
+    float* win = td_smem;                                // [ROWS][S] units
+    float* mid = win + G::ROWS * p.S * CH;               // [ovl*CH] (+16 pad)
+    float* ramp1 = mid + p.ovl * CH + 16;                // [ovl] cross-fade weights (stereo)
+    float* ramp2 = ramp1 + p.ovl;
+    __shared__ Best wave_best[4];
+    __shared__ int s_off, s_nan0;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const long long s = blockIdx.x;
+    const float* sbase = in.base + s * in.ss;
+    float* obase = out.base + s * out.ss;
+
+    if (p.begin0 || !mid_state) {
+        for (int i = tid; i < p.ovl * CH; i += kTdThreads) mid[i] = 0.0f;
+    } else {
+        for (int i = tid; i < p.ovl * CH; i += kTdThreads) mid[i] = mid_state[s * (long long)(p.ovl * CH) + i];
+    }
+    for (int i = tid; i < 16; i += kTdThreads) mid[p.ovl * CH + i] = 0.0f;
+    if (CH == 2 && tid == 0) {
+        const float step = 1.0f / (float)p.ovl;
+        float f1 = 0.0f, f2 = 1.0f;
+        for (int i = 0; i < p.ovl; i++) {
+            ramp1[i] = f1;
+            ramp2[i] = f2;
+            f1 += step;
+            f2 -= step;
+        }
+    }
+
+    const int pp = lane / G::LANES, bl = lane % G::LANES;
+    const int b = w * G::LANES + bl;
+    const int c0 = G::R * b + pp;                        // this thread's candidates: c0 + P*q, q = 0..3
+    const int wave_c0 = G::R * (w * G::LANES);           // smallest candidate of the wave
+    const float* xrow = win + (pp * p.S + b) * CH;
+
+    long long ip = p.ip0, op = p.op0;
+    double skip = p.skip0;
+    bool begin = p.begin0 != 0;
+
+#pragma unroll 1
+    for (long long k = 0; k < p.nseq; k++) {
+        int offset = 0;
+        if (!begin) {
+            // ---- stage the seek window [ip, ip + seekl + ovl)
+            const int nunits = p.seekl + p.ovl;
+            for (int u = tid; u < nunits; u += kTdThreads) {
+                const int row = u % G::R, col = u / G::R;
+                float x[CH];
+#pragma unroll
+                for (int c = 0; c < CH; c++) x[c] = ld_frame(in, sbase, ip + u, c);
+#pragma unroll
+                for (int c = 0; c < CH; c++) win[(row * p.S + col) * CH + c] = x[c];
+                if (row < G::P - 1 && col >= 1) {
+#pragma unroll
+                    for (int c = 0; c < CH; c++) win[((G::R + row) * p.S + col - 1) * CH + c] = x[c];
+                }
+            }
+            if (tid == 0) s_nan0 = 0;
+            __syncthreads();
+
+            // ---- score the candidates
+            Best mine{-__builtin_inf(), 0x7fffffff};
+            if (wave_c0 < p.seekl) {
+                float sc[4][4], sn[4][4];
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+#pragma unroll
+                    for (int l = 0; l < 4; l++) sc[q][l] = sn[q][l] = 0.0f;
+                float M[4][4];
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+#pragma unroll
+                    for (int l = 0; l < 4; l++) M[e][l] = 0.0f;
+                const int gsteps = (ng + 3 + 3) / 4;
+#pragma unroll 1
+                for (int g = 0; g < gsteps; g++) {
+                    const bool full = (4 * g >= 3) && (4 * g + 3 < ng);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int Gs = 4 * g + e;
+                        float X[4], Q[4];
+#pragma unroll
+                        for (int m = 0; m < G::P; m++)
+#pragma unroll
+                            for (int c = 0; c < CH; c++) X[m * CH + c] = xrow[((G::P * e + m) * p.S + g) * CH + c];
+#pragma unroll
+                        for (int l = 0; l < 4; l++) Q[l] = X[l] * X[l];
+                        {
+                            const float4 mv = *reinterpret_cast<const float4*>(mid + 4 * (Gs < ng ? Gs : ng));
+                            M[e][0] = mv.x; M[e][1] = mv.y; M[e][2] = mv.z; M[e][3] = mv.w;
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const int j = Gs - q;
+                            if (full || (j >= 0 && j < ng)) {
+                                const int me = (e - q) & 3;
+#pragma unroll
+                                for (int l = 0; l < 4; l++) {
+                                    sc[q][l] = sc[q][l] + X[l] * M[me][l];
+                                    sn[q][l] = sn[q][l] + Q[l];
+                                }
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int cand = c0 + G::P * q;
+                    const float norm = ((sn[q][0] + sn[q][1]) + sn[q][2]) + sn[q][3];
+                    const float sum = ((sc[q][0] + sc[q][1]) + sc[q][2]) + sc[q][3];
+                    double c = (double)sum / __builtin_sqrt(norm < 1e-9 ? 1.0 : (double)norm);
+                    const double u = (double)(2 * cand - p.seekl) / (double)p.seekl;
+                    c = (c + 0.1) * (1.0 - 0.25 * u * u);
+                    if (cand < p.seekl) {
+                        if (cand == 0 && c != c) s_nan0 = 1;
+                        if (c > mine.v) mine = Best{c, cand};
+                    }
+                }
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                Best o;
+                o.v = __shfl_xor(mine.v, d);
+                o.i = __shfl_xor(mine.i, d);
+                mine = better(mine, o);
+            }
+            if (lane == 0) wave_best[w] = mine;
+            __syncthreads();
+            if (tid == 0) {
+                Best r = better(better(wave_best[0], wave_best[1]), better(wave_best[2], wave_best[3]));
+                // a NaN score at offset 0 can never be beaten (every later comparison is false)
+                int o = (s_nan0 || r.i == 0x7fffffff) ? 0 : r.i;
+                s_off = o;
+                if (offs_dbg) offs_dbg[s * offs_stride + k - 1 + (p.begin0 ? 0 : 1)] = o;
+            }
+            __syncthreads();
+            const int best = s_off;
+
+            // ---- cross-fade the candidate into the stored tail
+            for (int i = tid; i < p.ovl && op + i < p.out_limit; i += kTdThreads) {
+                const int u = best + i;
+                const float* xu = win + ((u % G::R) * p.S + u / G::R) * CH;
+                if (CH == 2) {
+                    const float f1 = ramp1[i], f2 = ramp2[i];
+#pragma unroll
+                    for (int c = 0; c < CH; c++)
+                        obase[c * out.cs + (op + i - out.origin) * out.fs] = xu[c] * f1 + mid[i * CH + c] * f2;
+                } else {
+                    const float m1 = (float)i, m2 = (float)(p.ovl - i);
+                    obase[(op + i - out.origin) * out.fs] = (xu[0] * m1 + mid[i] * m2) / (float)p.ovl;
+                }
+            }
+            op += p.ovl;
+            offset = best + p.ovl;
+        } else {
+            // first sequence of a stream: nothing to fade into; the missing overlap is charged to the skip accumulator
+            begin = false;
+            skip -= (double)p.first_skip;
+            if (skip <= -p.nominal_skip) skip = -p.nominal_skip;
+        }
+        // ---- body of the sequence
+        for (int i = tid; i < p.body && op + i < p.out_limit; i += kTdThreads) {
+#pragma unroll
+            for (int c = 0; c < CH; c++)
+                obase[c * out.cs + (op + i - out.origin) * out.fs] = ld_frame(in, sbase, ip + offset + i, c);
+        }
+        op += p.body;
+        __syncthreads();                                 // the cross-fade has read the old tail
+        for (int i = tid; i < p.ovl; i += kTdThreads) {
+#pragma unroll
+            for (int c = 0; c < CH; c++) mid[i * CH + c] = ld_frame(in, sbase, ip + offset + p.body + i, c);
+        }
+        skip += p.nominal_skip;
+        const int adv = (int)skip;
+        skip -= (double)adv;
+        ip += adv;
+        __syncthreads();
+    }
+    if (mid_state) {
+        for (int i = tid; i < p.ovl * CH; i += kTdThreads) mid_state[s * (long long)(p.ovl * CH) + i] = mid[i];
+    }
+}
+
+static int td_row_stride(int ch, int ovl)
+{
+    const int P = 4 / ch, R = 4 * P;
+    const int ng = ovl * ch / 4;
+    // furthest unit any thread touches: candidate base up to R*255/P.. plus the sliding steps
+    const int max_unit = R * (kTdThreads / P) + P * (ng + 7) + P;
+    int S = max_unit / R + 2;
+    if (ch == 1) {
+        while (S % 64 != 16) S++;                        // quarter-waves on disjoint bank ranges
+    }
+    return S;
+}
+
+int st_launch_td(nae_ctx* ctx, const StCfg& c, const StView& in, const TdRange& r, const StOut& out, size_t n_streams,
+                 float* mid_state, int32_t* offs_dbg, long long offs_stride)
+{
+    if (r.nseq <= 0 || n_streams == 0) return NAE_OK;
+    if (c.seekl > 1024 || c.seekl < 1 || c.ovl % 8 != 0 || c.ovl < 16) return nae_fail(ctx, NAE_ERR_INVALID, "WSOLA geometry");
+    TdParams p;
+    p.ovl = c.ovl; p.seekl = c.seekl; p.body = c.body; p.first_skip = c.first_skip;
+    p.nominal_skip = c.nominal_skip;
+    p.ip0 = r.ip0; p.op0 = r.op0; p.nseq = r.nseq; p.skip0 = r.skip0; p.begin0 = r.begin0; p.out_limit = r.out_limit;
+    p.S = td_row_stride(c.ch, c.ovl);
+    const int rows = (c.ch == 2) ? TdGeo<2>::ROWS : TdGeo<1>::ROWS;
+    const size_t lds = ((size_t)rows * p.S * c.ch + (size_t)c.ovl * c.ch + 16 + 2 * (size_t)c.ovl) * sizeof(float);
+    if (lds > 60 * 1024) return nae_fail(ctx, NAE_ERR_INVALID, "WSOLA window does not fit LDS");
+    if (c.ch == 2)
+        NAE_KLAUNCH(ctx, "st_td_kernel", (st_td_kernel<2>), dim3((unsigned)n_streams), dim3(kTdThreads), lds, ctx->stream, in, p,
+                    out, mid_state, offs_dbg, offs_stride);
+    else
+        NAE_KLAUNCH(ctx, "st_td_kernel", (st_td_kernel<1>), dim3((unsigned)n_streams), dim3(kTdThreads), lds, ctx->stream, in, p,
+                    out, mid_state, offs_dbg, offs_stride);
+    return nae_check(ctx, hipGetLastError(), "st_td_kernel");
+}
+
+// ------------------------------------------------------------------ AA: 64-tap FIR
+constexpr int kAaTile = 1024;                 // outputs per workgroup (4 per thread)
+constexpr int kAaRow = (kAaTile + kAaLen) / 4 + 1;
+struct AaParams {
+    float h[kAaLen];
+    long long j0, j1;
+};
+
+template <int CH>
+__global__ __launch_bounds__(256) void st_aa_kernel(StView in, AaParams p, StOut out)
+{
+    __shared__ float tile[4 * kAaRow * CH];
+    const int tid = threadIdx.x;
+    const long long s = blockIdx.y;
+    const long long jt = p.j0 + (long long)blockIdx.x * kAaTile;
+    const float* sbase = in.base + s * in.ss;
+    float* obase = out.base + s * out.ss;
+    for (int u = tid; u < kAaTile + kAaLen; u += 256) {
+#pragma unroll
+        for (int c = 0; c < CH; c++) tile[((u & 3) * kAaRow + (u >> 2)) * CH + c] = ld_frame(in, sbase, jt + u, c);
+    }
+    __syncthreads();
+    const long long j = jt + 4 * tid;
+    if (j >= p.j1) return;
+    if (CH == 2) {
+        float ev[4][2], od[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; i++) ev[i][0] = ev[i][1] = od[i][0] = od[i][1] = 0.0f;
+#pragma unroll
+        for (int m = 0; m < kAaLen + 3; m++) {
+            const float2 x = *reinterpret_cast<const float2*>(tile + ((m & 3) * kAaRow + tid + (m >> 2)) * 2);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int k = m - i;
+                if (k >= 0 && k < kAaLen) {
+                    if ((k & 1) == 0) {
+                        ev[i][0] = ev[i][0] + x.x * p.h[k];
+                        ev[i][1] = ev[i][1] + x.y * p.h[k];
+                    } else {
+                        od[i][0] = od[i][0] + x.x * p.h[k];
+                        od[i][1] = od[i][1] + x.y * p.h[k];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (j + i < p.j1) {
+                obase[(j + i - out.origin) * out.fs] = od[i][0] + ev[i][0];
+                obase[out.cs + (j + i - out.origin) * out.fs] = od[i][1] + ev[i][1];
+            }
+        }
+    } else {
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int m = 0; m < kAaLen + 3; m++) {
+            const float x = tile[(m & 3) * kAaRow + tid + (m >> 2)];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int k = m - i;
+                if (k >= 0 && k < kAaLen) acc[i] += (double)(x * p.h[k]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (j + i < p.j1) obase[(j + i - out.origin) * out.fs] = (float)acc[i];
+    }
+}
+
+int st_launch_aa(nae_ctx* ctx, const StCfg& c, const StView& in, long long j0, long long j1, const StOut& out,
+                 size_t n_streams)
+{
+    if (j1 <= j0 || n_streams == 0) return NAE_OK;
+    AaParams p;
+    for (int k = 0; k < kAaLen; k++) p.h[k] = c.aa[k];
+    p.j0 = j0; p.j1 = j1;
+    const unsigned tiles = (unsigned)((j1 - j0 + kAaTile - 1) / kAaTile);
+    for (size_t s0 = 0; s0 < n_streams; s0 += 65535) {
+        const unsigned ns = (unsigned)((n_streams - s0 < 65535) ? n_streams - s0 : 65535);
+        StView vin = in;
+        vin.base += (long long)s0 * in.ss;
+        StOut vout = out;
+        vout.base += (long long)s0 * out.ss;
+        if (c.ch == 2)
+            NAE_KLAUNCH(ctx, "st_aa_kernel", (st_aa_kernel<2>), dim3(tiles, ns), dim3(256), 0, ctx->stream, vin, p, vout);
+        else
+            NAE_KLAUNCH(ctx, "st_aa_kernel", (st_aa_kernel<1>), dim3(tiles, ns), dim3(256), 0, ctx->stream, vin, p, vout);
+    }
+    return nae_check(ctx, hipGetLastError(), "st_aa_kernel");
+}
+
+// ------------------------------------------------------------------ CU: cubic transposer
+template <int CH>
+__global__ __launch_bounds__(256) void st_cu_kernel(StView in, const long long* __restrict__ pos, const float* __restrict__ fr,
+                                                    long long tab_origin, long long n0, long long n1, StOut out)
+{
+    const long long n = n0 + (long long)blockIdx.x * 256 + threadIdx.x;
+    if (n >= n1) return;
+    const long long s = blockIdx.y;
+    const long long a = pos[n - tab_origin];
+    const float x2 = fr[n - tab_origin], x1 = x2 * x2, x0 = x1 * x2, x3 = 1.0f;
+    const float y0 = ((-0.5f * x0 + 1.0f * x1) + -0.5f * x2) + 0.0f * x3;
+    const float y1 = ((1.5f * x0 + -2.5f * x1) + 0.0f * x2) + 1.0f * x3;
+    const float y2 = ((-1.5f * x0 + 2.0f * x1) + 0.5f * x2) + 0.0f * x3;
+    const float y3 = ((0.5f * x0 + -0.5f * x1) + 0.0f * x2) + 0.0f * x3;
+    const float* sbase = in.base + s * in.ss;
+    float* obase = out.base + s * out.ss;
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        const float p0 = ld_frame(in, sbase, a, c), p1 = ld_frame(in, sbase, a + 1, c);
+        const float p2 = ld_frame(in, sbase, a + 2, c), p3 = ld_frame(in, sbase, a + 3, c);
+        obase[c * out.cs + (n - out.origin) * out.fs] = ((y0 * p0 + y1 * p1) + y2 * p2) + y3 * p3;
+    }
+}
+
+int st_launch_cu(nae_ctx* ctx, const StCfg& c, const StView& in, const long long* d_pos, const float* d_fract,
+                 long long tab_origin, long long n0, long long n1, const StOut& out, size_t n_streams)
+{
+    if (n1 <= n0 || n_streams == 0) return NAE_OK;
+    const unsigned blocks = (unsigned)((n1 - n0 + 255) / 256);
+    for (size_t s0 = 0; s0 < n_streams; s0 += 65535) {
+        const unsigned ns = (unsigned)((n_streams - s0 < 65535) ? n_streams - s0 : 65535);
+        StView vin = in;
+        vin.base += (long long)s0 * in.ss;
+        StOut vout = out;
+        vout.base += (long long)s0 * out.ss;
+        if (c.ch == 2)
+            NAE_KLAUNCH(ctx, "st_cu_kernel", (st_cu_kernel<2>), dim3(blocks, ns), dim3(256), 0, ctx->stream, vin, d_pos, d_fract,
+                        tab_origin, n0, n1, vout);
+        else
+            NAE_KLAUNCH(ctx, "st_cu_kernel", (st_cu_kernel<1>), dim3(blocks, ns), dim3(256), 0, ctx->stream, vin, d_pos, d_fract,
+                        tab_origin, n0, n1, vout);
+    }
+    return nae_check(ctx, hipGetLastError(), "st_cu_kernel");
+}
+
+} // namespace nae

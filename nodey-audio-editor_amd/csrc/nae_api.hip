@@ -214,6 +214,7 @@ int nae_ctx_destroy(nae_ctx* ctx)
     if (ctx->d_rs_tab) (void)hipFree(ctx->d_rs_tab);
     if (ctx->ws_phase) (void)hipFree(ctx->ws_phase);
     if (ctx->ws_mid) (void)hipFree(ctx->ws_mid);
+    nae_wsola_cache_free(ctx);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return NAE_OK;

@@ -24,6 +24,7 @@ struct nae_ctx {
     void* ws_mid = nullptr;   size_t ws_mid_bytes = 0;
     float* d_rs_tab = nullptr; double rs_tab_rate = 0.0;
     std::vector<float> h_rs_tab;
+    struct nae_wsola_cache* wsola_cache = nullptr;   // plan + workspaces of nae_wsola_block_f32 (nae_wsola.hip)
     int pv_tile = 0;             // frames per phase-vocoder tile; 0 = choose per call (nae_pick_pv_tile)
     // tuning / A-B switches, read once from the environment at context creation (tools/ab.sh)
     bool dbg_pv_lowocc = false;      // NAE_PV_LOWOCC: force the 2-waves-per-SIMD synth build
@@ -79,6 +80,9 @@ int nae_launch_resample(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig*
 int nae_ensure_rs_table(nae_ctx* ctx, double rate_eff);
 int nae_pick_pv_tile(nae_ctx* ctx, size_t frames, size_t n_sc);
 constexpr int kPhasePad = 520; // int32 per (stream-channel, tile) record in the phase workspace
+
+// nae_wsola.hip
+void nae_wsola_cache_free(nae_ctx* ctx);
 
 // kernels_nodes.hip
 int nae_launch_copy_sig(nae_ctx* ctx, const nae_sig* src, const nae_sig* dst, size_t S, int ch, size_t n_streams,

@@ -96,6 +96,23 @@ int orc_pv_synth_phase(const float* src_interleaved, size_t L, int ch, const orc
                        int32_t* qs);
 const float* orc_rs_table(double rate_eff); /* (PHASES+1) x TAPS, rebuilt on every call into a static buffer */
 
+/* ---- K7 option A (N1): SoundTouch-2.3.2-shaped WSOLA + anti-alias FIR + cubic transposer, streaming
+ *      (orc_wsola.c; call sites audio-velocity.cpp:369-385,403,298,427).  PARITY UNPINNED. ---- */
+typedef struct orc_st orc_st;
+int orc_st_create(int sample_rate, int ch, double rate, double pitch, orc_st** h);
+void orc_st_destroy(orc_st* s);
+void orc_st_put(orc_st* s, const float* interleaved, size_t n);
+size_t orc_st_available(const orc_st* s);
+size_t orc_st_receive(orc_st* s, float* dst, size_t max);
+void orc_st_flush(orc_st* s);
+size_t orc_st_offsets(const orc_st* s, int32_t* dst, size_t max); /* overlap offsets chosen so far; returns their count */
+void orc_st_params(const orc_st* s, int* v4);                     /* overlap, sequence, seek lengths, samples required */
+const float* orc_st_aa_coef(const orc_st* s);                     /* 64 taps */
+void orc_st_cubic_weights(float x, float* y4);
+size_t orc_st_out_bound(size_t L, double rate, double pitch);
+int orc_st_process_f32(const float* src_interleaved, size_t L, int ch, int sample_rate, double rate, double pitch,
+                       float* dst, size_t* out_len);
+
 /* ---- synthetic inputs: splitmix64(seed) -> u32 -> float(u>>8)*2^-23 - 1 ---- */
 void orc_fill_uniform(float* dst, size_t n, uint64_t seed);
 

@@ -46,6 +46,20 @@ def lib():
         L.orc_rs_table.restype = C.POINTER(C.c_float)
         L.orc_rs_table.argtypes = [C.c_double]
         L.orc_fill_uniform.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64]
+        L.orc_st_create.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_void_p)]
+        L.orc_st_destroy.argtypes = [C.c_void_p]
+        L.orc_st_put.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.orc_st_available.restype = C.c_size_t
+        L.orc_st_available.argtypes = [C.c_void_p]
+        L.orc_st_receive.restype = C.c_size_t
+        L.orc_st_receive.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.orc_st_flush.argtypes = [C.c_void_p]
+        L.orc_st_offsets.restype = C.c_size_t
+        L.orc_st_offsets.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.orc_st_params.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_st_aa_coef.restype = C.POINTER(C.c_float)
+        L.orc_st_aa_coef.argtypes = [C.c_void_p]
+        L.orc_st_cubic_weights.argtypes = [C.c_float, C.c_void_p]
         _lib = L
     return _lib
 
@@ -188,6 +202,78 @@ def pv_synth_phase(x, ch, rate, pitch):
     rc = lib().orc_pv_synth_phase(_p(x), L, ch, C.byref(pl), _p(qs))
     assert rc == 0
     return qs
+
+
+class SoundTouchChain:
+    """streaming handle of the SoundTouch-shaped oracle (orc_wsola.c)"""
+
+    def __init__(self, sample_rate, ch, rate, pitch):
+        self.h = C.c_void_p()
+        self.ch = ch
+        rc = lib().orc_st_create(sample_rate, ch, rate, pitch, C.byref(self.h))
+        if rc:
+            raise ValueError("orc_st_create rc=%d" % rc)
+
+    def close(self):
+        if self.h:
+            lib().orc_st_destroy(self.h)
+            self.h = C.c_void_p()
+
+    __del__ = close
+
+    def put(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        lib().orc_st_put(self.h, _p(x), x.size // self.ch)
+
+    def available(self):
+        return lib().orc_st_available(self.h)
+
+    def receive(self, n=None):
+        n = self.available() if n is None else n
+        out = np.empty(max(n, 1) * self.ch, np.float32)
+        got = lib().orc_st_receive(self.h, _p(out), n)
+        return out[: got * self.ch]
+
+    def flush(self):
+        lib().orc_st_flush(self.h)
+
+    def offsets(self):
+        n = lib().orc_st_offsets(self.h, None, 0)
+        a = np.empty(max(n, 1), np.int32)
+        lib().orc_st_offsets(self.h, _p(a), n)
+        return a[:n]
+
+    def params(self):
+        v = np.zeros(4, np.int32)
+        lib().orc_st_params(self.h, _p(v))
+        return dict(overlap=int(v[0]), sequence=int(v[1]), seek=int(v[2]), required=int(v[3]))
+
+    def aa_coef(self):
+        return np.ctypeslib.as_array(lib().orc_st_aa_coef(self.h), shape=(64,)).copy()
+
+
+def st_process(x, ch, sample_rate, rate, pitch, chunk=None, want_offsets=False):
+    """whole buffer through the SoundTouch-shaped chain: put (optionally in chunks: one size or a repeating list of
+    sizes, receiving what is ready after every put), flush, receive all"""
+    x = np.ascontiguousarray(x, np.float32)
+    st = SoundTouchChain(sample_rate, ch, rate, pitch)
+    L = x.size // ch
+    sizes = [L] if not chunk else (list(chunk) if isinstance(chunk, (list, tuple)) else [chunk])
+    outs = []
+    a = i = 0
+    while a < L:
+        step = max(min(sizes[i % len(sizes)], L - a), 1)
+        i += 1
+        st.put(x[a * ch:(a + step) * ch])
+        a += step
+        if chunk:
+            outs.append(st.receive())
+    st.flush()
+    outs.append(st.receive())
+    offs = st.offsets()
+    st.close()
+    y = np.concatenate(outs) if outs else np.zeros(0, np.float32)
+    return (y, offs) if want_offsets else y
 
 
 def fill_uniform(n, seed):
