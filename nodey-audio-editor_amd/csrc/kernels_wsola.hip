@@ -22,9 +22,49 @@ namespace nae {
 
 constexpr int kTdThreads = 256;
 
-__device__ __forceinline__ float ld_frame(const StView& v, const float* sbase, long long a, int k)
+// device-side views: the host views plus "interleaved stereo, 8-byte aligned" (one 8-byte access per frame)
+struct DView { StView v; int vec2; };
+struct DOut { StOut o; int vec2; };
+template <int CH> struct Frame { float x[CH]; };
+
+template <int CH>
+__device__ __forceinline__ Frame<CH> ld_frame(const DView& d, const float* sbase, long long a)
 {
-    return (a < v.valid_end) ? sbase[k * v.cs + (a - v.origin) * v.fs] : 0.0f;
+    Frame<CH> f;
+    if (a >= d.v.valid_end) {
+#pragma unroll
+        for (int c = 0; c < CH; c++) f.x[c] = 0.0f;
+    } else if (CH == 2 && d.vec2) {
+        const float2 t = *reinterpret_cast<const float2*>(sbase + (a - d.v.origin) * 2);
+        f.x[0] = t.x;
+        f.x[CH - 1] = t.y;
+    } else {
+#pragma unroll
+        for (int c = 0; c < CH; c++) f.x[c] = sbase[c * d.v.cs + (a - d.v.origin) * d.v.fs];
+    }
+    return f;
+}
+
+template <int CH>
+__device__ __forceinline__ void st_frame(const DOut& d, float* obase, long long a, const Frame<CH>& f)
+{
+    if (CH == 2 && d.vec2) {
+        *reinterpret_cast<float2*>(obase + (a - d.o.origin) * 2) = float2{f.x[0], f.x[CH - 1]};
+    } else {
+#pragma unroll
+        for (int c = 0; c < CH; c++) obase[c * d.o.cs + (a - d.o.origin) * d.o.fs] = f.x[c];
+    }
+}
+
+static DView dview(const StView& v, int ch)
+{
+    const bool vec = ch == 2 && v.cs == 1 && v.fs == 2 && (reinterpret_cast<uintptr_t>(v.base) & 7) == 0 && (v.ss & 1) == 0;
+    return DView{v, vec ? 1 : 0};
+}
+static DOut dout(const StOut& o, int ch)
+{
+    const bool vec = ch == 2 && o.cs == 1 && o.fs == 2 && (reinterpret_cast<uintptr_t>(o.base) & 7) == 0 && (o.ss & 1) == 0;
+    return DOut{o, vec ? 1 : 0};
 }
 
 struct TdParams {
@@ -55,7 +95,7 @@ __device__ __forceinline__ Best better(Best a, Best b)
 }
 
 template <int CH>
-__global__ __launch_bounds__(kTdThreads) void st_td_kernel(StView in, TdParams p, StOut out, float* __restrict__ mid_state,
+__global__ __launch_bounds__(kTdThreads) void st_td_kernel(DView in, TdParams p, DOut out, float* __restrict__ mid_state,
                                                           int32_t* __restrict__ offs_dbg, long long offs_stride)
 {
     using G = TdGeo<CH>;
@@ -70,8 +110,8 @@ __global__ __launch_bounds__(kTdThreads) void st_td_kernel(StView in, TdParams p
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const long long s = blockIdx.x;
-    const float* sbase = in.base + s * in.ss;
-    float* obase = out.base + s * out.ss;
+    const float* sbase = in.v.base + s * in.v.ss;
+    float* obase = out.o.base + s * out.o.ss;
 
     if (p.begin0 || !mid_state) {
         for (int i = tid; i < p.ovl * CH; i += kTdThreads) mid[i] = 0.0f;
@@ -108,14 +148,12 @@ __global__ __launch_bounds__(kTdThreads) void st_td_kernel(StView in, TdParams p
             const int nunits = p.seekl + p.ovl;
             for (int u = tid; u < nunits; u += kTdThreads) {
                 const int row = u % G::R, col = u / G::R;
-                float x[CH];
+                const Frame<CH> x = ld_frame<CH>(in, sbase, ip + u);
 #pragma unroll
-                for (int c = 0; c < CH; c++) x[c] = ld_frame(in, sbase, ip + u, c);
-#pragma unroll
-                for (int c = 0; c < CH; c++) win[(row * p.S + col) * CH + c] = x[c];
+                for (int c = 0; c < CH; c++) win[(row * p.S + col) * CH + c] = x.x[c];
                 if (row < G::P - 1 && col >= 1) {
 #pragma unroll
-                    for (int c = 0; c < CH; c++) win[((G::R + row) * p.S + col - 1) * CH + c] = x[c];
+                    for (int c = 0; c < CH; c++) win[((G::R + row) * p.S + col - 1) * CH + c] = x.x[c];
                 }
             }
             if (tid == 0) s_nan0 = 0;
@@ -203,15 +241,16 @@ __global__ __launch_bounds__(kTdThreads) void st_td_kernel(StView in, TdParams p
             for (int i = tid; i < p.ovl && op + i < p.out_limit; i += kTdThreads) {
                 const int u = best + i;
                 const float* xu = win + ((u % G::R) * p.S + u / G::R) * CH;
+                Frame<CH> y;
                 if (CH == 2) {
                     const float f1 = ramp1[i], f2 = ramp2[i];
 #pragma unroll
-                    for (int c = 0; c < CH; c++)
-                        obase[c * out.cs + (op + i - out.origin) * out.fs] = xu[c] * f1 + mid[i * CH + c] * f2;
+                    for (int c = 0; c < CH; c++) y.x[c] = xu[c] * f1 + mid[i * CH + c] * f2;
                 } else {
                     const float m1 = (float)i, m2 = (float)(p.ovl - i);
-                    obase[(op + i - out.origin) * out.fs] = (xu[0] * m1 + mid[i] * m2) / (float)p.ovl;
+                    y.x[0] = (xu[0] * m1 + mid[i] * m2) / (float)p.ovl;
                 }
+                st_frame<CH>(out, obase, op + i, y);
             }
             op += p.ovl;
             offset = best + p.ovl;
@@ -222,16 +261,14 @@ __global__ __launch_bounds__(kTdThreads) void st_td_kernel(StView in, TdParams p
             if (skip <= -p.nominal_skip) skip = -p.nominal_skip;
         }
         // ---- body of the sequence
-        for (int i = tid; i < p.body && op + i < p.out_limit; i += kTdThreads) {
-#pragma unroll
-            for (int c = 0; c < CH; c++)
-                obase[c * out.cs + (op + i - out.origin) * out.fs] = ld_frame(in, sbase, ip + offset + i, c);
-        }
+        for (int i = tid; i < p.body && op + i < p.out_limit; i += kTdThreads)
+            st_frame<CH>(out, obase, op + i, ld_frame<CH>(in, sbase, ip + offset + i));
         op += p.body;
         __syncthreads();                                 // the cross-fade has read the old tail
         for (int i = tid; i < p.ovl; i += kTdThreads) {
+            const Frame<CH> x = ld_frame<CH>(in, sbase, ip + offset + p.body + i);
 #pragma unroll
-            for (int c = 0; c < CH; c++) mid[i * CH + c] = ld_frame(in, sbase, ip + offset + p.body + i, c);
+            for (int c = 0; c < CH; c++) mid[i * CH + c] = x.x[c];
         }
         skip += p.nominal_skip;
         const int adv = (int)skip;
@@ -271,11 +308,11 @@ int st_launch_td(nae_ctx* ctx, const StCfg& c, const StView& in, const TdRange& 
     const size_t lds = ((size_t)rows * p.S * c.ch + (size_t)c.ovl * c.ch + 16 + 2 * (size_t)c.ovl) * sizeof(float);
     if (lds > 60 * 1024) return nae_fail(ctx, NAE_ERR_INVALID, "WSOLA window does not fit LDS");
     if (c.ch == 2)
-        NAE_KLAUNCH(ctx, "st_td_kernel", (st_td_kernel<2>), dim3((unsigned)n_streams), dim3(kTdThreads), lds, ctx->stream, in, p,
-                    out, mid_state, offs_dbg, offs_stride);
+        NAE_KLAUNCH(ctx, "st_td_kernel", (st_td_kernel<2>), dim3((unsigned)n_streams), dim3(kTdThreads), lds, ctx->stream,
+                    dview(in, 2), p, dout(out, 2), mid_state, offs_dbg, offs_stride);
     else
-        NAE_KLAUNCH(ctx, "st_td_kernel", (st_td_kernel<1>), dim3((unsigned)n_streams), dim3(kTdThreads), lds, ctx->stream, in, p,
-                    out, mid_state, offs_dbg, offs_stride);
+        NAE_KLAUNCH(ctx, "st_td_kernel", (st_td_kernel<1>), dim3((unsigned)n_streams), dim3(kTdThreads), lds, ctx->stream,
+                    dview(in, 1), p, dout(out, 1), mid_state, offs_dbg, offs_stride);
     return nae_check(ctx, hipGetLastError(), "st_td_kernel");
 }
 
@@ -288,63 +325,76 @@ struct AaParams {
 };
 
 template <int CH>
-__global__ __launch_bounds__(256) void st_aa_kernel(StView in, AaParams p, StOut out)
+__global__ __launch_bounds__(256) void st_aa_kernel(DView in, AaParams p, DOut out)
 {
     __shared__ float tile[4 * kAaRow * CH];
+    __shared__ __attribute__((aligned(16))) float hs[kAaLen];
     const int tid = threadIdx.x;
     const long long s = blockIdx.y;
     const long long jt = p.j0 + (long long)blockIdx.x * kAaTile;
-    const float* sbase = in.base + s * in.ss;
-    float* obase = out.base + s * out.ss;
+    const float* sbase = in.v.base + s * in.v.ss;
+    float* obase = out.o.base + s * out.o.ss;
     for (int u = tid; u < kAaTile + kAaLen; u += 256) {
+        const Frame<CH> x = ld_frame<CH>(in, sbase, jt + u);
 #pragma unroll
-        for (int c = 0; c < CH; c++) tile[((u & 3) * kAaRow + (u >> 2)) * CH + c] = ld_frame(in, sbase, jt + u, c);
+        for (int c = 0; c < CH; c++) tile[((u & 3) * kAaRow + (u >> 2)) * CH + c] = x.x[c];
     }
+    if (tid < kAaLen) hs[tid] = p.h[tid];
     __syncthreads();
     const long long j = jt + 4 * tid;
     if (j >= p.j1) return;
-    if (CH == 2) {
-        float ev[4][2], od[4][2];
+    // 8 taps per trip: frames m = kb .. kb+10 feed outputs i = 0..3 with tap k = m - i.  Every accumulator still sees
+    // its taps in increasing order (the order is observable: results are compared bit for bit).
+    float ev[4][CH], od[4][CH];
+    double acc[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) ev[i][0] = ev[i][1] = od[i][0] = od[i][1] = 0.0f;
+    for (int i = 0; i < 4; i++) {
+        acc[i] = 0.0;
 #pragma unroll
-        for (int m = 0; m < kAaLen + 3; m++) {
-            const float2 x = *reinterpret_cast<const float2*>(tile + ((m & 3) * kAaRow + tid + (m >> 2)) * 2);
+        for (int c = 0; c < CH; c++) ev[i][c] = od[i][c] = 0.0f;
+    }
+#pragma unroll 1
+    for (int kb = 0; kb < kAaLen; kb += 8) {
+        float x[11][CH], h[8];
+#pragma unroll
+        for (int t = 0; t < 11; t++)
+#pragma unroll
+            for (int c = 0; c < CH; c++) x[t][c] = tile[((t & 3) * kAaRow + tid + (kb >> 2) + (t >> 2)) * CH + c];
+        {
+            const float4 h0 = *reinterpret_cast<const float4*>(hs + kb), h1 = *reinterpret_cast<const float4*>(hs + kb + 4);
+            h[0] = h0.x; h[1] = h0.y; h[2] = h0.z; h[3] = h0.w; h[4] = h1.x; h[5] = h1.y; h[6] = h1.z; h[7] = h1.w;
+        }
+#pragma unroll
+        for (int t = 0; t < 11; t++)
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const int k = m - i;
-                if (k >= 0 && k < kAaLen) {
-                    if ((k & 1) == 0) {
-                        ev[i][0] = ev[i][0] + x.x * p.h[k];
-                        ev[i][1] = ev[i][1] + x.y * p.h[k];
+                const int k = t - i;
+                if (k >= 0 && k < 8) {
+                    if (CH == 2) {
+                        // SSE stereo order: even and odd taps are summed separately
+#pragma unroll
+                        for (int c = 0; c < CH; c++) {
+                            if ((k & 1) == 0) ev[i][c] = ev[i][c] + x[t][c] * h[k];
+                            else od[i][c] = od[i][c] + x[t][c] * h[k];
+                        }
                     } else {
-                        od[i][0] = od[i][0] + x.x * p.h[k];
-                        od[i][1] = od[i][1] + x.y * p.h[k];
+                        acc[i] += (double)(x[t][0] * h[k]);      // generic mono order: float products summed in double
                     }
                 }
             }
-        }
+    }
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            if (j + i < p.j1) {
-                obase[(j + i - out.origin) * out.fs] = od[i][0] + ev[i][0];
-                obase[out.cs + (j + i - out.origin) * out.fs] = od[i][1] + ev[i][1];
+    for (int i = 0; i < 4; i++) {
+        if (j + i < p.j1) {
+            Frame<CH> y;
+            if (CH == 2) {
+#pragma unroll
+                for (int c = 0; c < CH; c++) y.x[c] = od[i][c] + ev[i][c];
+            } else {
+                y.x[0] = (float)acc[i];
             }
+            st_frame<CH>(out, obase, j + i, y);
         }
-    } else {
-        double acc[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int m = 0; m < kAaLen + 3; m++) {
-            const float x = tile[(m & 3) * kAaRow + tid + (m >> 2)];
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int k = m - i;
-                if (k >= 0 && k < kAaLen) acc[i] += (double)(x * p.h[k]);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-            if (j + i < p.j1) obase[(j + i - out.origin) * out.fs] = (float)acc[i];
     }
 }
 
@@ -363,17 +413,19 @@ int st_launch_aa(nae_ctx* ctx, const StCfg& c, const StView& in, long long j0, l
         StOut vout = out;
         vout.base += (long long)s0 * out.ss;
         if (c.ch == 2)
-            NAE_KLAUNCH(ctx, "st_aa_kernel", (st_aa_kernel<2>), dim3(tiles, ns), dim3(256), 0, ctx->stream, vin, p, vout);
+            NAE_KLAUNCH(ctx, "st_aa_kernel", (st_aa_kernel<2>), dim3(tiles, ns), dim3(256), 0, ctx->stream, dview(vin, 2), p,
+                        dout(vout, 2));
         else
-            NAE_KLAUNCH(ctx, "st_aa_kernel", (st_aa_kernel<1>), dim3(tiles, ns), dim3(256), 0, ctx->stream, vin, p, vout);
+            NAE_KLAUNCH(ctx, "st_aa_kernel", (st_aa_kernel<1>), dim3(tiles, ns), dim3(256), 0, ctx->stream, dview(vin, 1), p,
+                        dout(vout, 1));
     }
     return nae_check(ctx, hipGetLastError(), "st_aa_kernel");
 }
 
 // ------------------------------------------------------------------ CU: cubic transposer
 template <int CH>
-__global__ __launch_bounds__(256) void st_cu_kernel(StView in, const long long* __restrict__ pos, const float* __restrict__ fr,
-                                                    long long tab_origin, long long n0, long long n1, StOut out)
+__global__ __launch_bounds__(256) void st_cu_kernel(DView in, const long long* __restrict__ pos, const float* __restrict__ fr,
+                                                    long long tab_origin, long long n0, long long n1, DOut out)
 {
     const long long n = n0 + (long long)blockIdx.x * 256 + threadIdx.x;
     if (n >= n1) return;
@@ -384,14 +436,14 @@ __global__ __launch_bounds__(256) void st_cu_kernel(StView in, const long long* 
     const float y1 = ((1.5f * x0 + -2.5f * x1) + 0.0f * x2) + 1.0f * x3;
     const float y2 = ((-1.5f * x0 + 2.0f * x1) + 0.5f * x2) + 0.0f * x3;
     const float y3 = ((0.5f * x0 + -0.5f * x1) + 0.0f * x2) + 0.0f * x3;
-    const float* sbase = in.base + s * in.ss;
-    float* obase = out.base + s * out.ss;
+    const float* sbase = in.v.base + s * in.v.ss;
+    float* obase = out.o.base + s * out.o.ss;
+    const Frame<CH> p0 = ld_frame<CH>(in, sbase, a), p1 = ld_frame<CH>(in, sbase, a + 1);
+    const Frame<CH> p2 = ld_frame<CH>(in, sbase, a + 2), p3 = ld_frame<CH>(in, sbase, a + 3);
+    Frame<CH> y;
 #pragma unroll
-    for (int c = 0; c < CH; c++) {
-        const float p0 = ld_frame(in, sbase, a, c), p1 = ld_frame(in, sbase, a + 1, c);
-        const float p2 = ld_frame(in, sbase, a + 2, c), p3 = ld_frame(in, sbase, a + 3, c);
-        obase[c * out.cs + (n - out.origin) * out.fs] = ((y0 * p0 + y1 * p1) + y2 * p2) + y3 * p3;
-    }
+    for (int c = 0; c < CH; c++) y.x[c] = ((y0 * p0.x[c] + y1 * p1.x[c]) + y2 * p2.x[c]) + y3 * p3.x[c];
+    st_frame<CH>(out, obase, n, y);
 }
 
 int st_launch_cu(nae_ctx* ctx, const StCfg& c, const StView& in, const long long* d_pos, const float* d_fract,
@@ -406,11 +458,11 @@ int st_launch_cu(nae_ctx* ctx, const StCfg& c, const StView& in, const long long
         StOut vout = out;
         vout.base += (long long)s0 * out.ss;
         if (c.ch == 2)
-            NAE_KLAUNCH(ctx, "st_cu_kernel", (st_cu_kernel<2>), dim3(blocks, ns), dim3(256), 0, ctx->stream, vin, d_pos, d_fract,
-                        tab_origin, n0, n1, vout);
+            NAE_KLAUNCH(ctx, "st_cu_kernel", (st_cu_kernel<2>), dim3(blocks, ns), dim3(256), 0, ctx->stream, dview(vin, 2), d_pos,
+                        d_fract, tab_origin, n0, n1, dout(vout, 2));
         else
-            NAE_KLAUNCH(ctx, "st_cu_kernel", (st_cu_kernel<1>), dim3(blocks, ns), dim3(256), 0, ctx->stream, vin, d_pos, d_fract,
-                        tab_origin, n0, n1, vout);
+            NAE_KLAUNCH(ctx, "st_cu_kernel", (st_cu_kernel<1>), dim3(blocks, ns), dim3(256), 0, ctx->stream, dview(vin, 1), d_pos,
+                        d_fract, tab_origin, n0, n1, dout(vout, 1));
     }
     return nae_check(ctx, hipGetLastError(), "st_cu_kernel");
 }

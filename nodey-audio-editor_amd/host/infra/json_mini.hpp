@@ -34,6 +34,8 @@ namespace Json
 		bool isNull() const { return std::holds_alternative<std::monostate>(scalar) && members.empty(); }
 		bool isBool() const { return std::holds_alternative<bool>(scalar); }
 		bool isInt() const { return std::holds_alternative<int>(scalar); }
+		bool isString() const { return std::holds_alternative<std::string>(scalar); }
+		std::string asString() const { return isString() ? std::get<std::string>(scalar) : std::string(); }
 		// JsonCpp: isDouble() is true for every numeric value
 		bool isDouble() const { return std::holds_alternative<double>(scalar) || std::holds_alternative<int>(scalar); }
 		bool asBool() const { return isBool() ? std::get<bool>(scalar) : asDouble() != 0.0; }

@@ -6,6 +6,15 @@
 
 namespace processor
 {
+	const char* algorithm_name(Stretch_algorithm a) { return a == Stretch_algorithm::Soundtouch ? "soundtouch" : "vocoder"; }
+
+	Stretch_algorithm algorithm_from_json(const Json::Value& value)
+	{
+		if (value.isMember("algorithm") && value["algorithm"].isString() && value["algorithm"].asString() == "soundtouch")
+			return Stretch_algorithm::Soundtouch;
+		return Stretch_algorithm::Vocoder;
+	}
+
 	namespace
 	{
 		std::vector<infra::Processor::Pin_attribute> io_pins()
@@ -56,11 +65,43 @@ namespace processor
 			return out;
 		}
 
-		// soundtouch_process_payload, audio-velocity.cpp:265-443, with nae_stretch in SoundTouch's place
+		// the object soundtouch_process_payload talks to: the phase-vocoder handle (default) or the
+		// SoundTouch-shaped WSOLA chain, chosen by the node's "algorithm" key
+		struct Stretcher
+		{
+			nae_stretch* pv = nullptr;
+			nae_wsola* st = nullptr;
+			~Stretcher()
+			{
+				if (pv) nae_stretch_destroy(pv);
+				if (st) nae_wsola_destroy(st);
+			}
+			bool open() const { return pv != nullptr || st != nullptr; }
+			void create(Stretch_algorithm algo, int sample_rate, int channels, float velocity, float pitch)
+			{
+				if (algo == Stretch_algorithm::Soundtouch)
+					gpu::check(nae_wsola_create(gpu::context(), sample_rate, channels, velocity, pitch, &st), "nae_wsola_create");
+				else
+					gpu::check(nae_stretch_create(gpu::context(), sample_rate, channels, velocity, pitch, &pv), "nae_stretch_create");
+			}
+			size_t available() const { return pv ? nae_stretch_available(pv) : nae_wsola_available(st); }
+			void put(const float* samples, size_t n)
+			{
+				gpu::check(pv ? nae_stretch_put(pv, samples, n) : nae_wsola_put(st, samples, n), "stretch put");
+			}
+			void receive_host(float* dst, size_t max, size_t* got)
+			{
+				gpu::check(pv ? nae_stretch_receive_host(pv, dst, max, got) : nae_wsola_receive_host(st, dst, max, got), "stretch receive");
+			}
+			void flush() { gpu::check(pv ? nae_stretch_flush(pv) : nae_wsola_flush(st), "stretch flush"); }
+		};
+
+		// soundtouch_process_payload, audio-velocity.cpp:265-443, with a GPU handle in SoundTouch's place
 		void stretch_process_payload(
 			const std::map<std::string, std::shared_ptr<infra::Processor::Product>>& input,
 			const std::map<std::string, std::set<std::shared_ptr<infra::Processor::Product>>>& output,
-			const std::atomic<bool>& stop_token, float velocity, float pitch, const std::string& processor_name
+			const std::atomic<bool>& stop_token, float velocity, float pitch, const std::string& processor_name,
+			Stretch_algorithm algorithm
 		)
 		{
 			const auto input_item = infra::get_input_item<Audio_stream>(input, "input");
@@ -72,9 +113,7 @@ namespace processor
 					"Input item 'input' not found"
 				);
 			Audio_stream& input_stream = input_item.value().get();
-			nae_ctx* ctx = gpu::context();
-			nae_stretch* soundtouch = nullptr;
-			struct Guard { nae_stretch*& h; ~Guard() { if (h) nae_stretch_destroy(h); } } guard{soundtouch};
+			Stretcher soundtouch;
 			gpu::Device_buffer d_raw, d_f32;
 			bool input_stream_eof = false;
 			const double time_ratio = 1.0f / velocity;
@@ -86,7 +125,7 @@ namespace processor
 				std::vector<float> output_samples((size_t)count * channel_count);
 				size_t samples_read = 0;
 				gpu::wait(stop_token);
-				gpu::check(nae_stretch_receive_host(soundtouch, output_samples.data(), count, &samples_read), "nae_stretch_receive_host");
+				soundtouch.receive_host(output_samples.data(), count, &samples_read);
 				output_samples.resize(samples_read * channel_count);
 				auto new_frame = construct_audio_frame_float(output_samples, sample_rate, channel_count, (float)(time_seconds * 1000000));
 				time_seconds += double(samples_read) / sample_rate;
@@ -116,7 +155,7 @@ namespace processor
 					{
 						constexpr size_t max_queued_samples = 65536;
 						const Frame_data* frame = pop_result.value()->data();
-						if (soundtouch == nullptr)
+						if (!soundtouch.open())
 						{
 							if (frame->sample_rate < 8000 || frame->sample_rate > 48000)  // :371-379
 								throw infra::Processor::Runtime_error(
@@ -124,34 +163,31 @@ namespace processor
 									infra::fmt("%d requires a sample rate between 8000 and 48000 Hz.", frame->sample_rate),
 									infra::fmt("Sample rate: %d", frame->sample_rate)
 								);
-							gpu::check(
-								nae_stretch_create(ctx, frame->sample_rate, frame->ch_layout.nb_channels, velocity, pitch, &soundtouch),
-								"nae_stretch_create"
-							);
+							soundtouch.create(algorithm, frame->sample_rate, frame->ch_layout.nb_channels, velocity, pitch);
 							channel_count = frame->ch_layout.nb_channels;
 							time_seconds = frame->pts * av_q2d(frame->time_base);
 							sample_rate = frame->sample_rate;
 						}
-						while (!stop_token && nae_stretch_available(soundtouch) > max_queued_samples) nae_fiber::this_fiber::yield();
+						while (!stop_token && soundtouch.available() > max_queued_samples) nae_fiber::this_fiber::yield();
 						float* samples = upload_as_f32(frame, d_raw, d_f32);
-						gpu::check(nae_stretch_put(soundtouch, samples, frame->nb_samples), "nae_stretch_put");
+						soundtouch.put(samples, frame->nb_samples);
 						gpu::wait(stop_token);  // d_raw / d_f32 are reused for the next frame
 					}
 				}
-				if (soundtouch != nullptr)
+				if (soundtouch.open())
 				{
-					if (nae_stretch_available(soundtouch) == 0 && input_stream_eof && false) break;  // (:414 is subsumed by the flush branch)
+					// (:414 "numSamples() == 0 && eof -> break" is subsumed by the flush branch)
 					const uint32_t min_samples = time_ratio * 1152;
 					const uint32_t max_samples = time_ratio * 1152 * 3;
-					if (nae_stretch_available(soundtouch) > min_samples)
-						acquire_func((int)std::min<size_t>(nae_stretch_available(soundtouch), max_samples));
+					if (soundtouch.available() > min_samples)
+						acquire_func((int)std::min<size_t>(soundtouch.available(), max_samples));
 					else if (input_stream_eof)
 					{
-						gpu::check(nae_stretch_flush(soundtouch), "nae_stretch_flush");
+						soundtouch.flush();
 						// the reference emits ONE frame with everything that is left (:427-433); here flush() may release
 						// the whole stream, so it is cut into the same [min, max] chunks the steady state uses
-						while (!stop_token && nae_stretch_available(soundtouch) > 0)
-							acquire_func((int)std::min<size_t>(nae_stretch_available(soundtouch), std::max<uint32_t>(max_samples, 1)));
+						while (!stop_token && soundtouch.available() > 0)
+							acquire_func((int)std::min<size_t>(soundtouch.available(), std::max<uint32_t>(max_samples, 1)));
 						break;
 					}
 				}
@@ -177,7 +213,8 @@ namespace processor
 		const std::atomic<bool>& stop_token, std::any&
 	)
 	{
-		stretch_process_payload(input, output, stop_token, velocity, keep_pitch ? 1 / velocity : 1, get_processor_info().display_name);  // :452-459
+		stretch_process_payload(input, output, stop_token, velocity, keep_pitch ? 1 / velocity : 1, get_processor_info().display_name,
+								algorithm);  // :452-459
 	}
 
 	Json::Value Velocity_modifier::serialize() const
@@ -185,6 +222,7 @@ namespace processor
 		Json::Value value;
 		value["velocity"] = velocity;
 		value["keep_pitch"] = keep_pitch;
+		if (algorithm != Stretch_algorithm::Vocoder) value["algorithm"] = algorithm_name(algorithm);
 		return value;
 	}
 
@@ -192,6 +230,7 @@ namespace processor
 	{
 		if (value.isMember("velocity") && value["velocity"].isDouble()) velocity = value["velocity"].asFloat();
 		if (value.isMember("keep_pitch") && value["keep_pitch"].isBool()) keep_pitch = value["keep_pitch"].asBool();
+		algorithm = algorithm_from_json(value);
 	}
 
 	// ------------------------------------------------------------------------------------------ Pitch_modifier
@@ -208,18 +247,21 @@ namespace processor
 		const std::atomic<bool>& stop_token, std::any&
 	)
 	{
-		stretch_process_payload(input, output, stop_token, 1, std::pow(2.0f, pitch / 12.0f), get_processor_info().display_name);  // :469-476
+		stretch_process_payload(input, output, stop_token, 1, std::pow(2.0f, pitch / 12.0f), get_processor_info().display_name,
+								algorithm);  // :469-476
 	}
 
 	Json::Value Pitch_modifier::serialize() const
 	{
 		Json::Value value;
 		value["pitch"] = pitch;
+		if (algorithm != Stretch_algorithm::Vocoder) value["algorithm"] = algorithm_name(algorithm);
 		return value;
 	}
 	void Pitch_modifier::deserialize(const Json::Value& value)
 	{
 		if (value.isMember("pitch") && value["pitch"].isDouble()) pitch = value["pitch"].asFloat();
+		algorithm = algorithm_from_json(value);
 	}
 
 	// ------------------------------------------------------------------------------------------ Audio_spectrum

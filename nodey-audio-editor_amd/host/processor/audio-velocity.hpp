@@ -6,10 +6,18 @@
 
 namespace processor
 {
+	// Which GPU implementation stands in for SoundTouch.  The reference's JSON has no such key, so projects saved by
+	// it load as Vocoder (the phase vocoder BASELINE.json's north_star asks for); "algorithm": "soundtouch" selects
+	// the WSOLA + anti-alias FIR + cubic transposer chain restated from SoundTouch 2.3.2 (nae_wsola_*).
+	enum class Stretch_algorithm { Vocoder, Soundtouch };
+	const char* algorithm_name(Stretch_algorithm a);
+	Stretch_algorithm algorithm_from_json(const Json::Value& value);
+
 	class Velocity_modifier : public infra::Processor
 	{
 		float velocity = 1;
 		bool keep_pitch = false;
+		Stretch_algorithm algorithm = Stretch_algorithm::Vocoder;
 
 	  public:
 
@@ -29,6 +37,7 @@ namespace processor
 	class Pitch_modifier : public infra::Processor
 	{
 		float pitch = 0;  // semitones
+		Stretch_algorithm algorithm = Stretch_algorithm::Vocoder;
 
 	  public:
 

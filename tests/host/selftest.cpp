@@ -439,6 +439,40 @@ static void test_gpu_velocity_keep_pitch()
 	CHECK(rel_rms(got, ref) <= 1e-4, "velocity(keep pitch) within 1e-4 RMS: " << rel_rms(got, ref));
 }
 
+// "algorithm": "soundtouch" -> the WSOLA chain; frame-by-frame feeding gives the stream the oracle gives for the
+// same put sequence, bit for bit (the chain is chunk-invariant: tests/test_wsola_cpu.py)
+static void test_gpu_pitch_soundtouch_algorithm()
+{
+	const int S = 30000;
+	const float semis = 3.0f;
+	Runner r;
+	auto src = std::make_shared<Test_source>();
+	src->samples = uniform(S * 2, 21);
+	auto pitch = std::make_shared<Pitch_modifier>();
+	Json::Value v;
+	v["pitch"] = (double)semis;
+	v["algorithm"] = "soundtouch";
+	pitch->deserialize(v);
+	CHECK(pitch->serialize()["algorithm"].asString() == "soundtouch", "algorithm key round-trips");
+	auto sink = std::make_shared<Test_sink>();
+	r.add_node(1, src); r.add_node(2, pitch); r.add_node(3, sink);
+	r.add_link({1, "output", 2, "input"});
+	r.add_link({2, "output", 3, "input"});
+	CHECK(r.run(), "soundtouch-algorithm graph runs: " << r.get_processor_resources().at(2)->error_text);
+	const float p = std::pow(2.0f, semis / 12.0f);
+	orc_st* st = nullptr;
+	CHECK(orc_st_create(48000, 2, 1.0, (double)p, &st) == 0, "oracle create");
+	for (int a = 0; a < S; a += src->frame_size)
+		orc_st_put(st, src->samples.data() + 2 * a, (size_t)std::min(src->frame_size, S - a));
+	orc_st_flush(st);
+	std::vector<float> ref(orc_st_available(st) * 2);
+	orc_st_receive(st, ref.data(), ref.size() / 2);
+	orc_st_destroy(st);
+	const auto got = sink->interleaved();
+	CHECK(got.size() == ref.size() && got.size() == (size_t)S * 2, "soundtouch-algorithm output length " << got.size() << " vs " << ref.size());
+	CHECK(got.size() == ref.size() && std::equal(got.begin(), got.end(), ref.begin()), "soundtouch-algorithm output is bit-exact vs the oracle chain");
+}
+
 static void test_gpu_bimix_v2()
 {
 	const int S = 5000;
@@ -489,6 +523,7 @@ int main(int argc, char** argv)
 		test_gpu_amix_converted_input();
 		test_gpu_pitch_spectrum_fanout();
 		test_gpu_velocity_keep_pitch();
+		test_gpu_pitch_soundtouch_algorithm();
 		test_gpu_bimix_v2();
 	}
 	std::cout << (failures ? "SELFTEST FAILED " : "SELFTEST OK ") << mode << " failures=" << failures << "\n";
