@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--cpu-streams", type=int, default=128, help="streams the CPU-oracle baseline is timed on")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-alt", action="store_true", help="skip the side measurement of the SoundTouch-shaped pitch node")
     return ap.parse_args()
 
 
@@ -183,6 +184,32 @@ def main():
                   "frac_hbm_peak": round(chain_gbs / HBM_PEAK_GBS, 4)},
         "kernels": kern_report,
     }
+
+    # ---- the same pitch node with the SoundTouch-shaped WSOLA chain (K7 option A) instead of the phase vocoder:
+    # reported beside the headline, never part of `value`
+    if not a.no_alt and world == 1:
+        wpl = ctx.wsola_plan(48000, 2, 1.0, pitch, S)
+        wdst = nae.Sig.interleaved(d_pitch.ptr, wpl.out_len, 2)
+        assert wpl.out_len <= pl.out_len
+        ctx.wsola_block(48000, 1.0, pitch, g.mix_out, S, 2, n_streams, wdst)     # plan, table, workspaces
+        ctx.sync()
+        ctx.prof_reset()
+        ctx.prof_enable(True)
+        tw0 = time.perf_counter()
+        for _ in range(2):
+            ctx.wsola_block(48000, 1.0, pitch, g.mix_out, S, 2, n_streams, wdst)
+        ctx.sync()
+        w_ms = (time.perf_counter() - tw0) / 2 * 1e3
+        ctx.prof_enable(False)
+        wk = {k: round(v[0] / max(v[1], 1), 4) for k, v in ctx.prof_report().items()}
+        other = sum(v["avg_ms"] for k, v in kern_report.items() if not k.startswith(("pv_", "resample")))
+        out["pitch_node_soundtouch_algorithm"] = {
+            "what": "input->mix(2)->pitch->spectrum with the pitch node running the WSOLA + anti-alias FIR + cubic "
+                    "transposer chain restated from SoundTouch 2.3.2 (nae_wsola_block_f32) instead of the phase vocoder",
+            "pitch_node_ms": round(w_ms, 3), "kernels_avg_ms": wk, "sequences_per_stream": int(wpl.n_seq),
+            "graph_sample_frames_per_s": n_streams * S / ((w_ms + other) * 1e-3)}
+        ctx.graph4(g)                                        # restore the vocoder result for the parity check below
+        ctx.sync()
 
     # ---- CPU baseline (reported, not the target): the oracle's restatement of the same graph, 1 thread
     if not a.no_cpu_baseline and world == 1:

@@ -170,6 +170,9 @@ struct PvParams {
     long long f_origin;   // first frame / output block of tile 0 (0 in block mode; > 0 when a stream is continued)
     long long f_stop;     // one past the last frame / block this launch is responsible for
     int skip_last;        // pass 1 only: the last tile's sum is not needed (nothing is carried on behind it)
+    int lockstep;         // synth: workgroup barrier every `lockstep` frames (power of two; 0 = never) so the channel waves
+                          // of a stream store their halves of an interleaved line close together: the halves then merge
+                          // in L2 instead of leaving for HBM as two partial writes
 };
 
 __device__ __forceinline__ long long frame_start(const PvParams& p, long long f)
@@ -592,6 +595,7 @@ __global__ __launch_bounds__(kThreads, 2) void pv_synth2_kernel(SigViewD src, Pv
 #pragma unroll 1
     for (long long f = f_first; f < f_end; f++) {
         const long long s = frame_start(p, f);
+        if (p.lockstep && (f & (p.lockstep - 1)) == 0) __builtin_amdgcn_s_barrier();   // terminated waves are not counted
 #pragma unroll
         for (int j = 0; j < 8; j++) va[j] = cf{nxt[j].x * win[j].x, nxt[j].y * win[j].y};
         if (f + 1 < f_end) load_frame_raw<kUnit>(nxt, in, frame_start(p, f + 1), lane);
@@ -895,6 +899,7 @@ static PvParams make_pv_params(const nae_stretch_plan& pl, size_t in_len, int ch
     p.f_stop = p.f_origin + cnt;
     p.n_tiles = (int)((cnt + tile - 1) / tile);
     p.skip_last = 0;
+    p.lockstep = 0;
     return p;
 }
 
@@ -962,6 +967,7 @@ int nae_launch_pv_synth(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig*
 #define NAE_SYNTH(U, O) NAE_KLAUNCH(ctx, "pv_synth_kernel", (pv_synth_kernel<U, O>), dim3(grid), dim3(kThreads), lds, ctx->stream, \
                                     to_view(src), p, items, phase_ws, to_out(out), tb)
     if (low_occ && !ctx->dbg_pv_no_pipeline) {
+        p.lockstep = (ch == 2 && out->frame_stride == 2) ? ctx->dbg_pv_lockstep : 0;
         const size_t lds2 = kLdsTables + kWaves * kLdsPerWavePv2;
         if (src->frame_stride == 1)
             NAE_KLAUNCH(ctx, "pv_synth_kernel", (pv_synth2_kernel<true>), dim3(grid), dim3(kThreads), lds2, ctx->stream, to_view(src),

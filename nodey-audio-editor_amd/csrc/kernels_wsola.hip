@@ -425,11 +425,14 @@ int st_launch_aa(nae_ctx* ctx, const StCfg& c, const StView& in, long long j0, l
 // ------------------------------------------------------------------ CU: cubic transposer
 template <int CH>
 __global__ __launch_bounds__(256) void st_cu_kernel(DView in, const long long* __restrict__ pos, const float* __restrict__ fr,
-                                                    long long tab_origin, long long n0, long long n1, DOut out)
+                                                    long long tab_origin, long long n0, long long n1, DOut out, unsigned n_streams)
 {
-    const long long n = n0 + (long long)blockIdx.x * 256 + threadIdx.x;
+    // output index fastest over the grid: each stream's reads and writes stay contiguous (the alternative — streams
+    // fastest, so that neighbours share a piece of the table in L2 — measured 9 % slower)
+    const unsigned blocks = gridDim.x / n_streams;
+    const long long s = blockIdx.x / blocks;
+    const long long n = n0 + (long long)(blockIdx.x % blocks) * 256 + threadIdx.x;
     if (n >= n1) return;
-    const long long s = blockIdx.y;
     const long long a = pos[n - tab_origin];
     const float x2 = fr[n - tab_origin], x1 = x2 * x2, x0 = x1 * x2, x3 = 1.0f;
     const float y0 = ((-0.5f * x0 + 1.0f * x1) + -0.5f * x2) + 0.0f * x3;
@@ -450,19 +453,23 @@ int st_launch_cu(nae_ctx* ctx, const StCfg& c, const StView& in, const long long
                  long long tab_origin, long long n0, long long n1, const StOut& out, size_t n_streams)
 {
     if (n1 <= n0 || n_streams == 0) return NAE_OK;
-    const unsigned blocks = (unsigned)((n1 - n0 + 255) / 256);
-    for (size_t s0 = 0; s0 < n_streams; s0 += 65535) {
-        const unsigned ns = (unsigned)((n_streams - s0 < 65535) ? n_streams - s0 : 65535);
+    const long long blocks = (n1 - n0 + 255) / 256;
+    // one launch covers at most 2^31 - 1 workgroups: chunk the streams if a batch is larger than that
+    const size_t max_ns = (size_t)(0x7fffffffll / blocks);
+    if (max_ns == 0) return nae_fail(ctx, NAE_ERR_INVALID, "cubic transposer: range too long for one launch");
+    for (size_t s0 = 0; s0 < n_streams; s0 += max_ns) {
+        const unsigned ns = (unsigned)((n_streams - s0 < max_ns) ? n_streams - s0 : max_ns);
         StView vin = in;
         vin.base += (long long)s0 * in.ss;
         StOut vout = out;
         vout.base += (long long)s0 * out.ss;
+        const unsigned grid = (unsigned)(blocks * ns);
         if (c.ch == 2)
-            NAE_KLAUNCH(ctx, "st_cu_kernel", (st_cu_kernel<2>), dim3(blocks, ns), dim3(256), 0, ctx->stream, dview(vin, 2), d_pos,
-                        d_fract, tab_origin, n0, n1, dout(vout, 2));
+            NAE_KLAUNCH(ctx, "st_cu_kernel", (st_cu_kernel<2>), dim3(grid), dim3(256), 0, ctx->stream, dview(vin, 2), d_pos, d_fract,
+                        tab_origin, n0, n1, dout(vout, 2), ns);
         else
-            NAE_KLAUNCH(ctx, "st_cu_kernel", (st_cu_kernel<1>), dim3(blocks, ns), dim3(256), 0, ctx->stream, dview(vin, 1), d_pos,
-                        d_fract, tab_origin, n0, n1, dout(vout, 1));
+            NAE_KLAUNCH(ctx, "st_cu_kernel", (st_cu_kernel<1>), dim3(grid), dim3(256), 0, ctx->stream, dview(vin, 1), d_pos, d_fract,
+                        tab_origin, n0, n1, dout(vout, 1), ns);
     }
     return nae_check(ctx, hipGetLastError(), "st_cu_kernel");
 }

@@ -115,6 +115,19 @@ keep = (Lp - 4096) * 2
 err = rr(gy[:keep], ref[:keep])
 add("C3", "pitch +3 st, 1 stream x 1 h stereo (phase vocoder + transposer)", L3, ms, 16, f"rel-RMS {err:.1e} on first 20 s",
     f"oracle 1 thread: {Lp / cpu_s:.3e} sf/s (20 s sample)")
+# the same hour through the SoundTouch-shaped chain (K7 option A): one stream = one workgroup walking ~46 000 WSOLA
+# sequences in order (the sequential dependency of the algorithm), so this is the latency-bound corner of that path
+wpl = ctx.wsola_plan(48000, 2, 1.0, p, L3)
+ms_w = timed(lambda: ctx.wsola_block(48000, 1.0, p, src, L3, 2, 1, dst), reps=1, warm=1)
+Lw = 5 * 48000
+t0 = time.perf_counter()
+ref_w = orc.st_process(xin[: Lw * 2], 2, 48000, 1.0, p)
+cpu_w = time.perf_counter() - t0
+gw = np.empty((Lw - 48000) * 2, np.float32)
+ctx._ck(ctx.lib.nae_memcpy_d2h(ctx.h, gw.ctypes.data, d_y.ptr, gw.nbytes)); ctx.sync()
+okw = np.array_equal(gw, ref_w[: gw.size])       # a prefix: output frame n depends on input up to ~n + one sequence only
+add("C3 (SoundTouch-shaped)", f"pitch +3 st, 1 stream x 1 h stereo, WSOLA + FIR + cubic, {wpl.n_seq} sequences in series", L3, ms_w, 16,
+    "bit-exact on first 4 s" if okw else "MISMATCH", f"oracle 1 thread: {Lw / cpu_w:.3e} sf/s (5 s sample)")
 d_x.free(); d_y.free()
 
 # ---------------------------------------------------------------- C4: 4-node graph on 8 ch x 96 kHz = 4 stereo pairs, 60 s

@@ -22,7 +22,9 @@ def norm(name):
     """'void nae::pv_synth_kernel<true, 2>(nae::SigViewD, ...)' -> 'pv_synth_kernel'"""
     import re
     name = name.split("(")[0].replace("void ", "").replace("nae::", "").strip()
-    return re.sub(r"<.*", "", name)
+    name = re.sub(r"<.*", "", name)
+    # variants that bench.py / the in-library profiler report under one launch label
+    return {"pv_synth2_kernel": "pv_synth_kernel", "spectrum_stereo_kernel": "spectrum_kernel"}.get(name, name)
 
 
 def per_kernel(path):
@@ -31,7 +33,9 @@ def per_kernel(path):
     for r in csv.DictReader(open(path)):
         k = norm(r["Kernel_Name"])
         d[k].append(float(r["Counter_Value"]))
-        meta[k] = {"vgpr": int(r["VGPR_Count"]), "lds": int(r["LDS_Block_Size"]), "wg": int(r["Workgroup_Size"])}
+        g = lambda *names: next(r[n] for n in names if n in r)       # rocprofv3 csv vs rocpd2csv column names
+        meta[k] = {"vgpr": int(g("VGPR_Count", "Vgpr_Count")), "lds": int(g("LDS_Block_Size", "Lds_Block_Size")),
+                   "wg": int(g("Workgroup_Size"))}
     return {k: sorted(v)[len(v) // 2] for k, v in d.items()}, meta
 
 
@@ -44,7 +48,8 @@ def main():
     w, _ = per_kernel(write)
     dur = {}
     for r in csv.DictReader(open(stats)):
-        dur[norm(r["Name"])] = dur.get(norm(r["Name"]), 0.0) + float(r["AverageNs"]) / 1e6
+        avg = r["AverageNs"] if "AverageNs" in r else r["Average (Nsec)"]
+        dur[norm(r["Name"])] = dur.get(norm(r["Name"]), 0.0) + float(avg) / 1e6
     traffic = {}
     lines = [f"# {tag}: HBM traffic per launch from rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes)", "",
              f"sample-frames per launch: {sf}", "",
