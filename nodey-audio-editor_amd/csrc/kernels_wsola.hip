@@ -20,8 +20,6 @@
 
 namespace nae {
 
-constexpr int kTdThreads = 256;
-
 // device-side views: the host views plus "interleaved stereo, 8-byte aligned" (one 8-byte access per frame)
 struct DView { StView v; int vec2; };
 struct DOut { StOut o; int vec2; };
@@ -76,13 +74,21 @@ struct TdParams {
     int S;          // LDS row stride of the window, in units
 };
 
-// geometry of the transposed window: CH = 2: unit = one frame (8 B), 2 units per 4-float group, 8 rows (+1 copy)
-//                                     CH = 1: unit = one sample,      4 units per group,        16 rows (+3 copies)
-template <int CH> struct TdGeo {
-    static constexpr int P = 4 / CH;          // units per group = spacing of the candidates one thread owns
-    static constexpr int R = 4 * P;           // rows
-    static constexpr int ROWS = R + P - 1;    // with the wrapped copies
-    static constexpr int LANES = 64 / P;      // lanes that share one p
+// geometry of the transposed window.  A thread owns NC candidates P units apart (P = 4 / CH units make one 4-float
+// group: 2 frames for stereo, 4 samples for mono), a workgroup of 1024 / NC threads covers 1024 candidates.
+// Unit u lives at row u mod R, column u div R with R = NC * P; rows R .. R+P-2 repeat rows 0 .. P-2 one column on, so
+// that a group that wraps around the rows is still read at a fixed row offset.
+//   NC = 4: 256 threads, one window read feeds 4 candidates (throughput shape: several streams per CU)
+//   NC = 2: 512 threads, 8 waves per stream (latency shape: at most ~2 streams per CU, down to a lone stream)
+template <int CH, int NC> struct TdGeo {
+    static constexpr int P = 4 / CH;
+    static constexpr int R = NC * P;
+    static constexpr int ROWS = R + P - 1;
+    static constexpr int LANES = 64 / P;          // lanes that share one p
+    static constexpr int THREADS = 1024 / NC;
+    static constexpr int WAVES = THREADS / 64;
+    static constexpr int PF = (1344 + THREADS - 1) / THREADS;   // window frames one thread stages (seek + overlap <= 1344)
+    static constexpr int CP = 4;                  // frames one thread has in flight while copying the body
 };
 
 struct Best {
@@ -94,31 +100,33 @@ __device__ __forceinline__ Best better(Best a, Best b)
     return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
 }
 
-template <int CH>
-__global__ __launch_bounds__(kTdThreads) void st_td_kernel(DView in, TdParams p, DOut out, float* __restrict__ mid_state,
-                                                          int32_t* __restrict__ offs_dbg, long long offs_stride)
+template <int CH, int NC>
+__global__ __launch_bounds__(1024 / NC, 4) void st_td_kernel(DView in, TdParams p, DOut out, float* __restrict__ mid_state,
+                                                         int32_t* __restrict__ offs_dbg, long long offs_stride)
 {
-    using G = TdGeo<CH>;
+    using G = TdGeo<CH, NC>;
+    constexpr int T = G::THREADS;
     extern __shared__ __attribute__((aligned(16))) float td_smem[];
     const int ng = p.ovl * CH / 4;                       // 4-float groups per candidate
     float* win = td_smem;                                // [ROWS][S] units
     float* mid = win + G::ROWS * p.S * CH;               // [ovl*CH] (+16 pad)
     float* ramp1 = mid + p.ovl * CH + 16;                // [ovl] cross-fade weights (stereo)
     float* ramp2 = ramp1 + p.ovl;
-    __shared__ Best wave_best[4];
+    __shared__ Best wave_best[G::WAVES];
     __shared__ int s_off, s_nan0;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const long long s = blockIdx.x;
     const float* sbase = in.v.base + s * in.v.ss;
     float* obase = out.o.base + s * out.o.ss;
+    const int nunits = p.seekl + p.ovl;
 
     if (p.begin0 || !mid_state) {
-        for (int i = tid; i < p.ovl * CH; i += kTdThreads) mid[i] = 0.0f;
+        for (int i = tid; i < p.ovl * CH; i += T) mid[i] = 0.0f;
     } else {
-        for (int i = tid; i < p.ovl * CH; i += kTdThreads) mid[i] = mid_state[s * (long long)(p.ovl * CH) + i];
+        for (int i = tid; i < p.ovl * CH; i += T) mid[i] = mid_state[s * (long long)(p.ovl * CH) + i];
     }
-    for (int i = tid; i < 16; i += kTdThreads) mid[p.ovl * CH + i] = 0.0f;
+    for (int i = tid; i < 16; i += T) mid[p.ovl * CH + i] = 0.0f;
     if (CH == 2 && tid == 0) {
         const float step = 1.0f / (float)p.ovl;
         float f1 = 0.0f, f2 = 1.0f;
@@ -132,53 +140,81 @@ __global__ __launch_bounds__(kTdThreads) void st_td_kernel(DView in, TdParams p,
 
     const int pp = lane / G::LANES, bl = lane % G::LANES;
     const int b = w * G::LANES + bl;
-    const int c0 = G::R * b + pp;                        // this thread's candidates: c0 + P*q, q = 0..3
+    const int c0 = G::R * b + pp;                        // this thread's candidates: c0 + P*q, q < NC
     const int wave_c0 = G::R * (w * G::LANES);           // smallest candidate of the wave
     const float* xrow = win + (pp * p.S + b) * CH;
+
+    // window of the sequence that starts at frame `at`: global -> registers -> LDS.  The loads are issued one
+    // sequence ahead (the positions do not depend on the audio) so their latency hides behind the scoring loop.
+    Frame<CH> pf[G::PF];
+    auto window_load = [&](long long at) {
+#pragma unroll
+        for (int j = 0; j < G::PF; j++) {
+            const int u = tid + j * T;
+            if (u < nunits) pf[j] = ld_frame<CH>(in, sbase, at + u);
+        }
+    };
+    auto window_store = [&]() {
+#pragma unroll
+        for (int j = 0; j < G::PF; j++) {
+            const int u = tid + j * T;
+            if (u < nunits) {
+                const int row = u % G::R, col = u / G::R;
+#pragma unroll
+                for (int c = 0; c < CH; c++) win[(row * p.S + col) * CH + c] = pf[j].x[c];
+                if (row < G::P - 1 && col >= 1) {
+#pragma unroll
+                    for (int c = 0; c < CH; c++) win[((G::R + row) * p.S + col - 1) * CH + c] = pf[j].x[c];
+                }
+            }
+        }
+    };
 
     long long ip = p.ip0, op = p.op0;
     double skip = p.skip0;
     bool begin = p.begin0 != 0;
+    if (!begin && p.nseq > 0) {
+        window_load(ip);
+        window_store();
+    }
+    if (tid == 0) s_nan0 = 0;
+    __syncthreads();
 
 #pragma unroll 1
     for (long long k = 0; k < p.nseq; k++) {
+        // where the next sequence starts (the library's skip bookkeeping, in its order of operations)
+        double skip_n = skip;
+        if (begin) {
+            skip_n -= (double)p.first_skip;
+            if (skip_n <= -p.nominal_skip) skip_n = -p.nominal_skip;
+        }
+        skip_n += p.nominal_skip;
+        const int adv = (int)skip_n;
+        skip_n -= (double)adv;
+        const long long ip_n = ip + adv;
+        const bool more = k + 1 < p.nseq;
+        // few streams per CU: fetch the next window now, so that its latency hides behind the scoring loop; with many
+        // streams other workgroups hide it and the 12 registers are better spent on occupancy
+        constexpr bool kAhead = NC < 4;
+        if (more && kAhead) window_load(ip_n);
+
         int offset = 0;
         if (!begin) {
-            // ---- stage the seek window [ip, ip + seekl + ovl)
-            const int nunits = p.seekl + p.ovl;
-            for (int u = tid; u < nunits; u += kTdThreads) {
-                const int row = u % G::R, col = u / G::R;
-                const Frame<CH> x = ld_frame<CH>(in, sbase, ip + u);
-#pragma unroll
-                for (int c = 0; c < CH; c++) win[(row * p.S + col) * CH + c] = x.x[c];
-                if (row < G::P - 1 && col >= 1) {
-#pragma unroll
-                    for (int c = 0; c < CH; c++) win[((G::R + row) * p.S + col - 1) * CH + c] = x.x[c];
-                }
-            }
-            if (tid == 0) s_nan0 = 0;
-            __syncthreads();
-
             // ---- score the candidates
             Best mine{-__builtin_inf(), 0x7fffffff};
             if (wave_c0 < p.seekl) {
-                float sc[4][4], sn[4][4];
+                float sc[NC][4], sn[NC][4], M[NC][4];
 #pragma unroll
-                for (int q = 0; q < 4; q++)
+                for (int q = 0; q < NC; q++)
 #pragma unroll
-                    for (int l = 0; l < 4; l++) sc[q][l] = sn[q][l] = 0.0f;
-                float M[4][4];
-#pragma unroll
-                for (int e = 0; e < 4; e++)
-#pragma unroll
-                    for (int l = 0; l < 4; l++) M[e][l] = 0.0f;
-                const int gsteps = (ng + 3 + 3) / 4;
+                    for (int l = 0; l < 4; l++) sc[q][l] = sn[q][l] = M[q][l] = 0.0f;
+                const int gsteps = (ng + NC - 1 + NC - 1) / NC;
 #pragma unroll 1
                 for (int g = 0; g < gsteps; g++) {
-                    const bool full = (4 * g >= 3) && (4 * g + 3 < ng);
+                    const bool full = (NC * g >= NC - 1) && (NC * g + NC - 1 < ng);
 #pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const int Gs = 4 * g + e;
+                    for (int e = 0; e < NC; e++) {
+                        const int Gs = NC * g + e;
                         float X[4], Q[4];
 #pragma unroll
                         for (int m = 0; m < G::P; m++)
@@ -191,10 +227,10 @@ __global__ __launch_bounds__(kTdThreads) void st_td_kernel(DView in, TdParams p,
                             M[e][0] = mv.x; M[e][1] = mv.y; M[e][2] = mv.z; M[e][3] = mv.w;
                         }
 #pragma unroll
-                        for (int q = 0; q < 4; q++) {
+                        for (int q = 0; q < NC; q++) {
                             const int j = Gs - q;
                             if (full || (j >= 0 && j < ng)) {
-                                const int me = (e - q) & 3;
+                                const int me = (e - q) & (NC - 1);
 #pragma unroll
                                 for (int l = 0; l < 4; l++) {
                                     sc[q][l] = sc[q][l] + X[l] * M[me][l];
@@ -205,7 +241,7 @@ __global__ __launch_bounds__(kTdThreads) void st_td_kernel(DView in, TdParams p,
                     }
                 }
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
+                for (int q = 0; q < NC; q++) {
                     const int cand = c0 + G::P * q;
                     const float norm = ((sn[q][0] + sn[q][1]) + sn[q][2]) + sn[q][3];
                     const float sum = ((sc[q][0] + sc[q][1]) + sc[q][2]) + sc[q][3];
@@ -228,17 +264,19 @@ __global__ __launch_bounds__(kTdThreads) void st_td_kernel(DView in, TdParams p,
             if (lane == 0) wave_best[w] = mine;
             __syncthreads();
             if (tid == 0) {
-                Best r = better(better(wave_best[0], wave_best[1]), better(wave_best[2], wave_best[3]));
+                Best r = wave_best[0];
+                for (int i = 1; i < G::WAVES; i++) r = better(r, wave_best[i]);
                 // a NaN score at offset 0 can never be beaten (every later comparison is false)
-                int o = (s_nan0 || r.i == 0x7fffffff) ? 0 : r.i;
+                const int o = (s_nan0 || r.i == 0x7fffffff) ? 0 : r.i;
                 s_off = o;
+                s_nan0 = 0;
                 if (offs_dbg) offs_dbg[s * offs_stride + k - 1 + (p.begin0 ? 0 : 1)] = o;
             }
             __syncthreads();
             const int best = s_off;
 
             // ---- cross-fade the candidate into the stored tail
-            for (int i = tid; i < p.ovl && op + i < p.out_limit; i += kTdThreads) {
+            for (int i = tid; i < p.ovl && op + i < p.out_limit; i += T) {
                 const int u = best + i;
                 const float* xu = win + ((u % G::R) * p.S + u / G::R) * CH;
                 Frame<CH> y;
@@ -255,38 +293,57 @@ __global__ __launch_bounds__(kTdThreads) void st_td_kernel(DView in, TdParams p,
             op += p.ovl;
             offset = best + p.ovl;
         } else {
-            // first sequence of a stream: nothing to fade into; the missing overlap is charged to the skip accumulator
+            // first sequence of a stream: nothing to fade into; the missing overlap was charged to the skip accumulator
             begin = false;
-            skip -= (double)p.first_skip;
-            if (skip <= -p.nominal_skip) skip = -p.nominal_skip;
         }
-        // ---- body of the sequence
-        for (int i = tid; i < p.body && op + i < p.out_limit; i += kTdThreads)
-            st_frame<CH>(out, obase, op + i, ld_frame<CH>(in, sbase, ip + offset + i));
-        op += p.body;
-        __syncthreads();                                 // the cross-fade has read the old tail
-        for (int i = tid; i < p.ovl; i += kTdThreads) {
-            const Frame<CH> x = ld_frame<CH>(in, sbase, ip + offset + p.body + i);
+        // ---- body of the sequence and the new tail: loads of CP frames per thread in flight before their stores
+        const long long bsrc = ip + offset;
+        Frame<CH> tail{};
+        if (tid < p.ovl) tail = ld_frame<CH>(in, sbase, bsrc + p.body + tid);
+        Frame<CH> tail2{};
+        if (tid + T < p.ovl) tail2 = ld_frame<CH>(in, sbase, bsrc + p.body + tid + T);
+        for (int i0 = 0; i0 < p.body; i0 += G::CP * T) {
+            Frame<CH> cp[G::CP];
 #pragma unroll
-            for (int c = 0; c < CH; c++) mid[i * CH + c] = x.x[c];
+            for (int j = 0; j < G::CP; j++) {
+                const int i = i0 + j * T + tid;
+                if (i < p.body) cp[j] = ld_frame<CH>(in, sbase, bsrc + i);
+            }
+#pragma unroll
+            for (int j = 0; j < G::CP; j++) {
+                const int i = i0 + j * T + tid;
+                if (i < p.body && op + i < p.out_limit) st_frame<CH>(out, obase, op + i, cp[j]);
+            }
         }
-        skip += p.nominal_skip;
-        const int adv = (int)skip;
-        skip -= (double)adv;
-        ip += adv;
+        op += p.body;
+        __syncthreads();                                 // the cross-fade has read the old tail and the old window
+        if (tid < p.ovl) {
+#pragma unroll
+            for (int c = 0; c < CH; c++) mid[tid * CH + c] = tail.x[c];
+        }
+        if (tid + T < p.ovl) {
+#pragma unroll
+            for (int c = 0; c < CH; c++) mid[(tid + T) * CH + c] = tail2.x[c];
+        }
+        if (more) {
+            if (!kAhead) window_load(ip_n);
+            window_store();
+        }
+        skip = skip_n;
+        ip = ip_n;
         __syncthreads();
     }
     if (mid_state) {
-        for (int i = tid; i < p.ovl * CH; i += kTdThreads) mid_state[s * (long long)(p.ovl * CH) + i] = mid[i];
+        for (int i = tid; i < p.ovl * CH; i += T) mid_state[s * (long long)(p.ovl * CH) + i] = mid[i];
     }
 }
 
-static int td_row_stride(int ch, int ovl)
+static int td_row_stride(int ch, int ovl, int nc)
 {
-    const int P = 4 / ch, R = 4 * P;
+    const int P = 4 / ch, R = nc * P;
     const int ng = ovl * ch / 4;
-    // furthest unit any thread touches: candidate base up to R*255/P.. plus the sliding steps
-    const int max_unit = R * (kTdThreads / P) + P * (ng + 7) + P;
+    // furthest column any thread touches: candidate base up to 1024 plus the sliding steps
+    const int max_unit = 1024 + P * (ng + 2 * nc) + P;
     int S = max_unit / R + 2;
     if (ch == 1) {
         while (S % 64 != 16) S++;                        // quarter-waves on disjoint bank ranges
@@ -298,21 +355,27 @@ int st_launch_td(nae_ctx* ctx, const StCfg& c, const StView& in, const TdRange& 
                  float* mid_state, int32_t* offs_dbg, long long offs_stride)
 {
     if (r.nseq <= 0 || n_streams == 0) return NAE_OK;
-    if (c.seekl > 1024 || c.seekl < 1 || c.ovl % 8 != 0 || c.ovl < 16) return nae_fail(ctx, NAE_ERR_INVALID, "WSOLA geometry");
+    if (c.seekl > 1024 || c.seekl < 1 || c.ovl % 8 != 0 || c.ovl < 16 || c.ovl > 512 || c.seekl + c.ovl > 1344)
+        return nae_fail(ctx, NAE_ERR_INVALID, "WSOLA geometry");
+    // several workgroups per CU: 4 candidates per thread (fewest instructions per candidate).  Up to about two
+    // workgroups per CU the search is latency-bound and 2 candidates per thread (twice the waves) is 1.2-1.6x faster;
+    // 1 per thread loses everywhere (measured: tools/td_sweep.sh) and stays only as a test shape.
+    int nc = n_streams >= 640 ? 4 : 2;
+    if (ctx->dbg_td_nc == 1 || ctx->dbg_td_nc == 2 || ctx->dbg_td_nc == 4) nc = ctx->dbg_td_nc;
     TdParams p;
     p.ovl = c.ovl; p.seekl = c.seekl; p.body = c.body; p.first_skip = c.first_skip;
     p.nominal_skip = c.nominal_skip;
     p.ip0 = r.ip0; p.op0 = r.op0; p.nseq = r.nseq; p.skip0 = r.skip0; p.begin0 = r.begin0; p.out_limit = r.out_limit;
-    p.S = td_row_stride(c.ch, c.ovl);
-    const int rows = (c.ch == 2) ? TdGeo<2>::ROWS : TdGeo<1>::ROWS;
+    p.S = td_row_stride(c.ch, c.ovl, nc);
+    const int P = 4 / c.ch, rows = nc * P + P - 1;
     const size_t lds = ((size_t)rows * p.S * c.ch + (size_t)c.ovl * c.ch + 16 + 2 * (size_t)c.ovl) * sizeof(float);
     if (lds > 60 * 1024) return nae_fail(ctx, NAE_ERR_INVALID, "WSOLA window does not fit LDS");
-    if (c.ch == 2)
-        NAE_KLAUNCH(ctx, "st_td_kernel", (st_td_kernel<2>), dim3((unsigned)n_streams), dim3(kTdThreads), lds, ctx->stream,
-                    dview(in, 2), p, dout(out, 2), mid_state, offs_dbg, offs_stride);
-    else
-        NAE_KLAUNCH(ctx, "st_td_kernel", (st_td_kernel<1>), dim3((unsigned)n_streams), dim3(kTdThreads), lds, ctx->stream,
-                    dview(in, 1), p, dout(out, 1), mid_state, offs_dbg, offs_stride);
+    const dim3 grid((unsigned)n_streams);
+#define NAE_TD(CHN, NCN) NAE_KLAUNCH(ctx, "st_td_kernel", (st_td_kernel<CHN, NCN>), grid, dim3(1024 / NCN), lds, ctx->stream, \
+                                     dview(in, CHN), p, dout(out, CHN), mid_state, offs_dbg, offs_stride)
+    if (c.ch == 2) { if (nc == 4) NAE_TD(2, 4); else if (nc == 2) NAE_TD(2, 2); else NAE_TD(2, 1); }
+    else { if (nc == 4) NAE_TD(1, 4); else if (nc == 2) NAE_TD(1, 2); else NAE_TD(1, 1); }
+#undef NAE_TD
     return nae_check(ctx, hipGetLastError(), "st_td_kernel");
 }
 

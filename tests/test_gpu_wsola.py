@@ -59,6 +59,25 @@ def test_block_is_bit_exact(ctx, nae, sr, ch, rate, pitch, L):
         assert np.array_equal(y[s].view(np.uint32), ref.view(np.uint32)), (s, int(np.count_nonzero(y[s] != ref)))
 
 
+@pytest.mark.parametrize("nc", [1, 2, 4])
+def test_every_search_shape_is_bit_exact(nae, nc, monkeypatch):
+    """the stretcher kernel has three shapes (4 / 2 / 1 candidate offsets per thread, picked by batch size); each must
+    give the oracle's offsets and samples"""
+    monkeypatch.setenv("NAE_TD_NC", str(nc))
+    c = nae.Context(0)
+    try:
+        for sr, ch, rate, pitch, L in ((48000, 2, 1.0, 2 ** (3 / 12), 40000), (48000, 1, 1.0, 0.8, 30000),
+                                       (22050, 1, 1.0, 0.8, 22050), (8000, 2, 1.2, 1.0, 12000)):
+            x = orc.fill_uniform(2 * L * ch, 50 + nc)
+            y, offs, _ = gpu_wsola(c, nae, x, ch, sr, rate, pitch, 2, want_offsets=True)
+            for s in range(2):
+                ref, ref_offs = orc.st_process(x.reshape(2, -1)[s], ch, sr, rate, pitch, want_offsets=True)
+                assert np.array_equal(offs[s], ref_offs), (nc, sr, ch, s)
+                assert np.array_equal(y[s].view(np.uint32), ref.view(np.uint32)), (nc, sr, ch, s)
+    finally:
+        c.close()
+
+
 def test_tonal_input_and_planar_source(ctx, nae):
     """a tonal signal has many near-equal correlation peaks: the exact evaluation order decides the splice"""
     sr, ch, L = 48000, 2, 96000
