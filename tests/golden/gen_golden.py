@@ -189,6 +189,20 @@ def main():
         k7[name] = orc.stretch(tone, 1, rate, pitch)
         k7[name + "_params"] = np.array([rate, pitch])
     np.savez_compressed(os.path.join(HERE, "k7_regression.npz"), **k7)
+
+    # ---- SoundTouch-shaped chain regression (ORACLE output of oracle/orc_wsola.c, not an independent pin: the
+    # library is absent, PARITY UNPINNED).  A two-tone stereo signal, 16 000 frames, the three stage orders.
+    Lw = 16000
+    n = np.arange(Lw)
+    st_in = np.stack([0.5 * np.sin(2 * np.pi * 440 * n / 48000) + 0.2 * np.sin(2 * np.pi * 1234.5 * n / 48000),
+                      0.4 * np.sin(2 * np.pi * 660 * n / 48000 + 1.0)], 1).astype(f32).reshape(-1)
+    ws = {"in": st_in}
+    for name, (rate, pitch) in {"pitch_up3": (1.0, 2 ** (3 / 12)), "tempo_1p25": (1.25, 0.8), "pitch_down4": (1.0, 2 ** (-4 / 12))}.items():
+        y, offs = orc.st_process(st_in, 2, 48000, rate, pitch, want_offsets=True)
+        ws[name] = y
+        ws[name + "_offsets"] = offs
+        ws[name + "_params"] = np.array([rate, pitch])
+    np.savez_compressed(os.path.join(HERE, "wsola_regression.npz"), **ws)
     print("wrote", [f for f in os.listdir(HERE) if f.endswith(".npz")])
 
 

@@ -186,3 +186,13 @@ def test_full_size_properties(ctx, nae):
     ref, ref_offs = orc.st_process(x, ch, sr, 1.0, 2 ** (3 / 12), want_offsets=True)
     assert np.array_equal(offs[0], ref_offs)
     assert np.array_equal(y[0].view(np.uint32), ref.view(np.uint32))
+
+
+def test_committed_fixture(ctx, nae, golden):
+    """GPU against the committed vectors (tests/golden/wsola_regression.npz), without the oracle in the loop"""
+    g = golden["wsola_regression"]
+    for name in ("pitch_up3", "tempo_1p25", "pitch_down4"):
+        rate, pitch = g[name + "_params"]
+        y, offs, _ = gpu_wsola(ctx, nae, g["in"], 2, 48000, float(rate), float(pitch), want_offsets=True)
+        assert np.array_equal(offs[0], g[name + "_offsets"]), name
+        assert np.array_equal(y[0].view(np.uint32), g[name].view(np.uint32)), name

@@ -107,3 +107,13 @@ def test_host_planner_rejects_what_the_reference_rejects(nae):
         nae.Context.wsola_plan(48000, 3, 1.0, 1.0, 1000)
     with pytest.raises(nae.NaeError):
         nae.Context.wsola_plan(48000, 2, 0.0, 1.0, 1000)
+
+
+def test_oracle_self_regression(golden):
+    """the committed output of this oracle (tests/golden/gen_golden.py) — catches unintended drift, pins nothing else"""
+    g = golden["wsola_regression"]
+    for name in ("pitch_up3", "tempo_1p25", "pitch_down4"):
+        rate, pitch = g[name + "_params"]
+        y, offs = orc.st_process(g["in"], 2, SR, rate, pitch, want_offsets=True)
+        assert np.array_equal(offs, g[name + "_offsets"]), name
+        assert np.array_equal(y.view(np.uint32), g[name].view(np.uint32)), name
