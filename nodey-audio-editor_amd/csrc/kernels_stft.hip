@@ -728,16 +728,19 @@ constexpr int kRsMaxSpan = 4096 + 32;            // staged source samples per ch
 
 // kStereo: the two channels are staged INTERLEAVED in LDS so one ds_read_b64 per tap feeds both accumulators
 // (the tap reads, not HBM, bound this kernel: 16 per channel-output).
-template <bool kStereo>
+// kStereo && NS > 1: one workgroup produces the same output tile for NS streams.  The 16 interpolated coefficients
+// of an output depend on its position only, so they are built once (8 x 128-bit LDS reads, 48 instructions) and
+// applied to NS streams: the kernel is bound by LDS reads + VALU, and both drop by about a third at NS = 4.
+template <bool kStereo, int NS>
 __global__ __launch_bounds__(256) void resample_tile_kernel(SigViewD src, RsParams p, const float* __restrict__ tab,
-                                                           OutViewD out, int span_alloc)
+                                                           OutViewD out, int span_alloc, long long n_streams)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char rs_smem[];
     float* stab = reinterpret_cast<float*>(rs_smem);                           // (PHASES+1) x kRsRow
-    float* stage = stab + (NAE_RS_PHASES + 1) * kRsRow;                        // stereo: [span_alloc][2]; else [ch][span_alloc]
+    float* stage = stab + (NAE_RS_PHASES + 1) * kRsRow;                        // stereo: [NS][span_alloc][2]; else [ch][span_alloc]
     for (int i = threadIdx.x; i < (NAE_RS_PHASES + 1) * NAE_RS_TAPS; i += 256)
         stab[(i / NAE_RS_TAPS) * kRsRow + (i % NAE_RS_TAPS)] = tab[i];
-    const long long s = blockIdx.y;
+    const long long s0 = (long long)blockIdx.y * NS;
     const long long j0 = p.j_begin + (long long)blockIdx.x * kRsOut;
     long long j1 = j0 + kRsOut;
     if (j1 > p.out_len) j1 = p.out_len;
@@ -749,39 +752,45 @@ __global__ __launch_bounds__(256) void resample_tile_kernel(SigViewD src, RsPara
     const long long m_lo = (idx_first - (NAE_RS_TAPS / 2 - 1)) & ~3ll;          // floor to 4 (arithmetic on negatives too)
     const long long m_hi = idx_last + NAE_RS_TAPS / 2 + 1;
     const int span = (int)(m_hi - m_lo);
-    const float* v0 = src.base + s * src.ss;
     if (kStereo) {
-        const float* v1 = v0 + src.cs;
-        const bool vec = (src.fs == 1) && (((reinterpret_cast<uintptr_t>(v0) | reinterpret_cast<uintptr_t>(v1)) & 15) == 0);
-        if (vec) {
-            for (int i = 4 * threadIdx.x; i < span; i += 4 * 256) {
-                const long long m = m_lo + i;
-                float4 x, y;
-                if (m >= 0 && m + 4 <= p.src_len) {
-                    x = *reinterpret_cast<const float4*>(v0 + m);
-                    y = *reinterpret_cast<const float4*>(v1 + m);
-                } else {
-                    float xe[4], ye[4];
+#pragma unroll 1
+        for (int k = 0; k < NS; k++) {
+            if (s0 + k >= n_streams) break;
+            const float* v0 = src.base + (s0 + k) * src.ss;
+            const float* v1 = v0 + src.cs;
+            float* stg = stage + (size_t)k * 2 * span_alloc;
+            const bool vec = (src.fs == 1) && (((reinterpret_cast<uintptr_t>(v0) | reinterpret_cast<uintptr_t>(v1)) & 15) == 0);
+            if (vec) {
+                for (int i = 4 * threadIdx.x; i < span; i += 4 * 256) {
+                    const long long m = m_lo + i;
+                    float4 x, y;
+                    if (m >= 0 && m + 4 <= p.src_len) {
+                        x = *reinterpret_cast<const float4*>(v0 + m);
+                        y = *reinterpret_cast<const float4*>(v1 + m);
+                    } else {
+                        float xe[4], ye[4];
 #pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const bool ok = (m + e >= 0) && (m + e < p.src_len);
-                        xe[e] = ok ? v0[m + e] : 0.0f;
-                        ye[e] = ok ? v1[m + e] : 0.0f;
+                        for (int e = 0; e < 4; e++) {
+                            const bool ok = (m + e >= 0) && (m + e < p.src_len);
+                            xe[e] = ok ? v0[m + e] : 0.0f;
+                            ye[e] = ok ? v1[m + e] : 0.0f;
+                        }
+                        x = float4{xe[0], xe[1], xe[2], xe[3]};
+                        y = float4{ye[0], ye[1], ye[2], ye[3]};
                     }
-                    x = float4{xe[0], xe[1], xe[2], xe[3]};
-                    y = float4{ye[0], ye[1], ye[2], ye[3]};
+                    *reinterpret_cast<float4*>(stg + 2 * i) = float4{x.x, y.x, x.y, y.y};
+                    *reinterpret_cast<float4*>(stg + 2 * i + 4) = float4{x.z, y.z, x.w, y.w};
                 }
-                *reinterpret_cast<float4*>(stage + 2 * i) = float4{x.x, y.x, x.y, y.y};
-                *reinterpret_cast<float4*>(stage + 2 * i + 4) = float4{x.z, y.z, x.w, y.w};
-            }
-        } else {
-            for (int i = threadIdx.x; i < span; i += 256) {
-                const long long m = m_lo + i;
-                const bool ok = m >= 0 && m < p.src_len;
-                *reinterpret_cast<float2*>(stage + 2 * i) = float2{ok ? v0[m * src.fs] : 0.0f, ok ? v1[m * src.fs] : 0.0f};
+            } else {
+                for (int i = threadIdx.x; i < span; i += 256) {
+                    const long long m = m_lo + i;
+                    const bool ok = m >= 0 && m < p.src_len;
+                    *reinterpret_cast<float2*>(stg + 2 * i) = float2{ok ? v0[m * src.fs] : 0.0f, ok ? v1[m * src.fs] : 0.0f};
+                }
             }
         }
     } else {
+        const float* v0 = src.base + s0 * src.ss;
         for (int c = 0; c < p.ch; c++) {
             const float* v = v0 + c * src.cs;
             float* st = stage + c * span_alloc;
@@ -792,8 +801,8 @@ __global__ __launch_bounds__(256) void resample_tile_kernel(SigViewD src, RsPara
         }
     }
     __syncthreads();
-    const bool out_pair = kStereo && (out.cs == 1) && (out.fs == 2) &&
-                          ((reinterpret_cast<uintptr_t>(out.base + s * out.ss) & 7) == 0);
+    const bool out_pair = kStereo && (out.cs == 1) && (out.fs == 2) && ((out.ss & 1) == 0) &&
+                          ((reinterpret_cast<uintptr_t>(out.base) & 7) == 0);
     for (long long j = j0 + threadIdx.x; j < j1; j += 256) {
         const unsigned long long lo = (unsigned long long)j * p.step_q32;
         const unsigned long long hi = __umul64hi((unsigned long long)j, p.step_q32);
@@ -813,14 +822,26 @@ __global__ __launch_bounds__(256) void resample_tile_kernel(SigViewD src, RsPara
             coef[4 * q + 3] = a.w + alpha * (b.w - a.w);
         }
         const int o = (int)(idx - (NAE_RS_TAPS / 2 - 1) - m_lo);
-        float acc[2] = {0.0f, 0.0f};
         if (kStereo) {
-            const float2* st = reinterpret_cast<const float2*>(stage) + o;
 #pragma unroll
-            for (int i = 0; i < NAE_RS_TAPS; i++) {
-                const float2 x = st[i];
-                acc[0] += coef[i] * x.x;
-                acc[1] += coef[i] * x.y;
+            for (int k = 0; k < NS; k++) {
+                if (s0 + k < n_streams) {
+                    const float2* st = reinterpret_cast<const float2*>(stage + (size_t)k * 2 * span_alloc) + o;
+                    float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < NAE_RS_TAPS; i++) {
+                        const float2 x = st[i];
+                        a0 += coef[i] * x.x;
+                        a1 += coef[i] * x.y;
+                    }
+                    float* ob = out.base + (s0 + k) * out.ss;
+                    if (out_pair) {
+                        *reinterpret_cast<float2*>(ob + 2 * j) = float2{a0, a1};
+                    } else {
+                        ob[j * out.fs] = a0;
+                        ob[out.cs + j * out.fs] = a1;
+                    }
+                }
             }
         } else {
             for (int c = 0; c < p.ch; c++) {
@@ -828,13 +849,8 @@ __global__ __launch_bounds__(256) void resample_tile_kernel(SigViewD src, RsPara
                 float a = 0.0f;
 #pragma unroll
                 for (int i = 0; i < NAE_RS_TAPS; i++) a += coef[i] * st[i];
-                acc[c] = a;
+                out.base[s0 * out.ss + c * out.cs + j * out.fs] = a;
             }
-        }
-        if (out_pair) {
-            *reinterpret_cast<float2*>(out.base + s * out.ss + 2 * j) = float2{acc[0], acc[1]};
-        } else {
-            for (int c = 0; c < p.ch; c++) out.base[s * out.ss + c * out.cs + j * out.fs] = acc[c];
         }
     }
 }
@@ -995,21 +1011,27 @@ int nae_launch_resample(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig*
     const long long span_need = (long long)(kRsOut * rho) + NAE_RS_TAPS + 8;
     const bool tiled = span_need <= kRsMaxSpan && !ctx->dbg_rs_direct;
     const int span_alloc = (int)((span_need + 3) & ~3ll);
-    const size_t lds = ((NAE_RS_PHASES + 1) * kRsRow + (size_t)ch * span_alloc) * sizeof(float);
+    // stereo batches: 4 streams per workgroup share the per-output coefficients (if their staging fits LDS)
+    const int group = (tiled && ch == 2 && n_streams >= 4 && span_alloc <= 1536 && !ctx->dbg_rs_single) ? 4 : 1;
+    const size_t lds = ((NAE_RS_PHASES + 1) * kRsRow + (size_t)ch * span_alloc * group) * sizeof(float);
     const unsigned gx = tiled ? (unsigned)((count + kRsOut - 1) / kRsOut) : (unsigned)((count + 255) / 256);
     // blockIdx.y is limited to 65535
-    for (size_t s0 = 0; s0 < n_streams; s0 += 65535) {
-        const size_t ns = (n_streams - s0 < 65535) ? n_streams - s0 : 65535;
+    const size_t per_launch = (size_t)65535 * group;
+    for (size_t s0 = 0; s0 < n_streams; s0 += per_launch) {
+        const size_t ns = (n_streams - s0 < per_launch) ? n_streams - s0 : per_launch;
         SigViewD sv = to_view(src);
         OutViewD ov = to_out(out);
         sv.base += (long long)s0 * sv.ss;
         ov.base += (long long)s0 * ov.ss;
-        if (tiled && ch == 2)
-            NAE_KLAUNCH(ctx, "resample_tile_kernel", (resample_tile_kernel<true>), dim3(gx, (unsigned)ns), dim3(256), lds, ctx->stream,
-                        sv, p, d_tab, ov, span_alloc);
+        if (tiled && ch == 2 && group == 4)
+            NAE_KLAUNCH(ctx, "resample_tile_kernel", (resample_tile_kernel<true, 4>), dim3(gx, (unsigned)((ns + 3) / 4)), dim3(256), lds,
+                        ctx->stream, sv, p, d_tab, ov, span_alloc, (long long)ns);
+        else if (tiled && ch == 2)
+            NAE_KLAUNCH(ctx, "resample_tile_kernel", (resample_tile_kernel<true, 1>), dim3(gx, (unsigned)ns), dim3(256), lds, ctx->stream,
+                        sv, p, d_tab, ov, span_alloc, (long long)ns);
         else if (tiled)
-            NAE_KLAUNCH(ctx, "resample_tile_kernel", (resample_tile_kernel<false>), dim3(gx, (unsigned)ns), dim3(256), lds, ctx->stream,
-                        sv, p, d_tab, ov, span_alloc);
+            NAE_KLAUNCH(ctx, "resample_tile_kernel", (resample_tile_kernel<false, 1>), dim3(gx, (unsigned)ns), dim3(256), lds, ctx->stream,
+                        sv, p, d_tab, ov, span_alloc, (long long)ns);
         else
             NAE_KLAUNCH(ctx, "resample_kernel", resample_kernel, dim3(gx, (unsigned)ns), dim3(256), 0, ctx->stream, sv, p,
                         (long long)ns, d_tab, ov);

@@ -186,6 +186,7 @@ int nae_ctx_create(int device, nae_ctx** out)
     if (const char* t = getenv("NAE_PV_TILE")) ctx->pv_tile = atoi(t) > 0 ? atoi(t) : 0;   // tuning knob (0 = automatic)
     ctx->dbg_pv_lowocc = getenv("NAE_PV_LOWOCC") != nullptr;
     ctx->dbg_pv_no_pipeline = getenv("NAE_PV_NO_PIPELINE") != nullptr;
+    ctx->dbg_rs_single = getenv("NAE_RS_SINGLE") != nullptr;
     if (const char* e = getenv("NAE_TD_NC")) ctx->dbg_td_nc = atoi(e);
     ctx->dbg_pv_lockstep = 8;
     if (const char* e = getenv("NAE_PV_LOCKSTEP")) {

@@ -151,10 +151,11 @@ def test_k7_batched_streams_are_independent(ctx, nae):
     p = 2 ** (3 / 12)
     got, pl = gpu_stretch(ctx, nae, x, ch, 1.0, p, n_streams)
     got = got.reshape(n_streams, -1)
-    for s in (0, 4, 8):
+    for s in range(n_streams):      # the transposer takes 4 streams per workgroup: every slot of a group, and a partial group
         one, _ = gpu_stretch(ctx, nae, x.reshape(n_streams, -1)[s].copy(), ch, 1.0, p)
         assert np.array_equal(one, got[s]), s
-        assert rel_rms(got[s], orc.stretch(x.reshape(n_streams, -1)[s], ch, 1.0, p)) <= TOL
+        if s in (0, 4, 8):
+            assert rel_rms(got[s], orc.stretch(x.reshape(n_streams, -1)[s], ch, 1.0, p)) <= TOL
 
 
 def test_k7_edge_lengths(ctx, nae):
