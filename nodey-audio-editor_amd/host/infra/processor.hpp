@@ -1,159 +1,140 @@
-// infra/processor.hpp — host-side mirror of the reference's plugin interface
-// (/root/reference/include/infra/processor.hpp:26-176): same class, member and function names, same argument
-// meaning, same error behaviour, so a processor written against the reference compiles against this header and
-// the GPU processors in ../processor/ drop into src/register.cpp unchanged.  Differences, all forced by the
-// toolchain of this image (g++ 11, no JsonCpp): std::format -> snprintf helper, Json::Value -> json_mini.hpp.
+// infra/processor.hpp — the plugin boundary of the editor, restated for the GPU processors.
+//
+// A node of the reference is a subclass of infra::Processor (/root/reference/include/infra/processor.hpp:26-130);
+// everything the GPU drop-ins touch of that contract is declared here under the reference's names so that
+// ../processor/*.cpp compile unchanged against the real header:
+//   Product (:32-39) · Pin_attribute (:42-49) · Info (:52-59) · Runtime_error (:64-77) · processor_map (:80)
+//   the pure virtuals (:86-113) · register_processor<T> (:116-129) · get_input_item / get_output_item (:134-176)
+// What differs is forced by this image's toolchain: Json::Value comes from json_mini.hpp, std::format from format.hpp.
+// The two GUI hooks (draw_title, draw_content) are empty here: drawing is the editor's business.
 #pragma once
 
 #include <any>
 #include <atomic>
-#include <cstdio>
 #include <functional>
 #include <map>
 #include <memory>
 #include <optional>
 #include <set>
-#include <stdexcept>
 #include <string>
 #include <typeinfo>
 #include <vector>
 
+#include "format.hpp"
 #include "json_mini.hpp"
 
 namespace infra
 {
 	using Id_t = int;
 
-	inline std::string fmt(const char* f) { return f; }
-	template <typename... Args>
-	std::string fmt(const char* f, Args... args)
-	{
-		char buf[1024];
-		std::snprintf(buf, sizeof buf, f, args...);
-		return buf;
-	}
-
-// reference: include/utility/logic-error-utility.hpp:2-12
-#define THROW_LOGIC_ERROR(...) \
-	{ throw std::logic_error(std::string(__FILE__) + "(" + std::to_string(__LINE__) + "): " + ::infra::fmt(__VA_ARGS__)); }
-
 	class Processor
 	{
 	  public:
 
-		// reference :32-39
+		// what travels along a link; nodes recover the concrete type through get_typeinfo()
 		class Product
 		{
 		  public:
 
-			Product() = default;
 			virtual ~Product() = default;
 			const std::type_info& get_typeinfo() const { return typeid(*this); }
 		};
 
-		// reference :42-49
+		using Product_ptr = std::shared_ptr<Product>;
+		using Input_map = std::map<std::string, Product_ptr>;
+		using Output_map = std::map<std::string, std::set<Product_ptr>>;
+
 		struct Pin_attribute
 		{
-			std::string identifier;
-			std::string display_name;
+			std::string identifier, display_name;
 			std::reference_wrapper<const std::type_info> type;
 			bool is_input;
-			std::function<std::shared_ptr<Product>()> generate_func;
+			std::function<Product_ptr()> generate_func;  // the runner makes one product per link with the PRODUCER's
 		};
 
-		// reference :52-59
 		struct Info
 		{
-			std::string identifier;
-			std::string display_name;
+			std::string identifier, display_name;
 			bool singleton = false;
 			std::function<std::unique_ptr<Processor>()> generate;
 			std::string description;
 		};
 
-		// reference :64-77 — message layout "{} (Detail: {}) (Explanation: {})"
-		struct Runtime_error : public std::runtime_error
+		// user-facing failure: what() reads "<message> (Detail: <detail>) (Explanation: <explanation>)"
+		struct Runtime_error : std::runtime_error
 		{
 			std::string message, explanation, detail;
 
-			Runtime_error(std::string message, std::string explanation, std::string detail = "") :
-				std::runtime_error(message + " (Detail: " + detail + ") (Explanation: " + explanation + ")"),
-				message(std::move(message)),
-				explanation(std::move(explanation)),
-				detail(std::move(detail))
+			Runtime_error(const std::string& msg, const std::string& why, const std::string& more = "") :
+				std::runtime_error(msg + " (Detail: " + more + ") (Explanation: " + why + ")"),
+				message(msg),
+				explanation(why),
+				detail(more)
 			{
 			}
 		};
 
-		static std::map<std::string, Processor::Info> processor_map;  // reference :80
+		static std::map<std::string, Info> processor_map;
 
-		Processor() = default;
 		virtual ~Processor() = default;
 
-		virtual std::vector<Processor::Pin_attribute> get_pin_attributes() const = 0;  // :86
-		virtual Processor::Info get_processor_info_non_static() const = 0;             // :90
-		virtual Json::Value serialize() const = 0;                                     // :93
-		virtual void deserialize(const Json::Value& value) = 0;                        // :96
-		virtual void draw_title() {}                                                   // :99  (GUI: no-op here)
-		virtual bool draw_content(bool readonly) { (void)readonly; return false; }      // :104 (GUI: no-op here)
-
-		// reference :108-113
+		virtual std::vector<Pin_attribute> get_pin_attributes() const = 0;
+		virtual Info get_processor_info_non_static() const = 0;
+		virtual Json::Value serialize() const = 0;
+		virtual void deserialize(const Json::Value& value) = 0;
+		virtual void draw_title() {}
+		virtual bool draw_content(bool /*readonly*/) { return false; }
 		virtual void process_payload(
-			const std::map<std::string, std::shared_ptr<Processor::Product>>& input,
-			const std::map<std::string, std::set<std::shared_ptr<Processor::Product>>>& output,
+			const Input_map& input,
+			const Output_map& output,
 			const std::atomic<bool>& stop_token,
 			std::any& user_data
 		) = 0;
 
-		// reference :116-129: duplicate identifier => logic_error
+		// one entry per identifier; registering an identifier twice is a programming error
 		template <typename T>
 		static void register_processor()
 		{
-			const Info processor_info = T::get_processor_info();
-			if (processor_map.count(processor_info.identifier))
-				THROW_LOGIC_ERROR("Processor with identifier '%s' already registered", processor_info.identifier.c_str());
-			processor_map[processor_info.identifier] = T::get_processor_info();
+			Info info = T::get_processor_info();
+			const std::string id = info.identifier;
+			if (!processor_map.emplace(id, std::move(info)).second)
+				THROW_LOGIC_ERROR("Processor with identifier '%s' already registered", id.c_str());
 		}
 	};
 
-	// reference :134-155
-	template <typename T>
-	std::optional<std::reference_wrapper<T>> get_input_item(
-		const std::map<std::string, std::shared_ptr<Processor::Product>>& input,
-		const std::string& key
-	)
+	namespace detail
 	{
-		const auto find = input.find(key);
-		if (find == input.end()) return std::nullopt;
-		if (find->second == nullptr) THROW_LOGIC_ERROR("Found nullptr in input map for key '%s'", key.c_str());
-		if (find->second->get_typeinfo() != typeid(T))
-			THROW_LOGIC_ERROR(
-				"Type mismatch in input map for key '%s', expected %s, got %s",
-				key.c_str(),
-				typeid(T).name(),
-				find->second->get_typeinfo().name()
-			);
-		return *std::dynamic_pointer_cast<T>(find->second);
-	}
-
-	// reference :158-176
-	template <typename T>
-	std::set<std::shared_ptr<T>> get_output_item(
-		const std::map<std::string, std::set<std::shared_ptr<Processor::Product>>>& output,
-		const std::string& key
-	)
-	{
-		const auto find = output.find(key);
-		if (find == output.end()) THROW_LOGIC_ERROR("Key '%s' not found in output map", key.c_str());
-		std::set<std::shared_ptr<T>> output_set;
-		for (auto& item : find->second)
+		// a product of the map as its concrete type; a null or foreign product is a wiring bug, not a user error
+		template <typename T>
+		std::shared_ptr<T> typed_product(const Processor::Product_ptr& product, const std::string& key, const char* side, bool check_type)
 		{
-			if (item == nullptr) THROW_LOGIC_ERROR("Found nullptr in output map for key '%s'", key.c_str());
-			output_set.emplace(std::dynamic_pointer_cast<T>(item));
+			if (!product) THROW_LOGIC_ERROR("Found nullptr in %s map for key '%s'", side, key.c_str());
+			if (check_type && product->get_typeinfo() != typeid(T))
+				THROW_LOGIC_ERROR("Type mismatch in %s map for key '%s', expected %s, got %s", side, key.c_str(), typeid(T).name(),
+								  product->get_typeinfo().name());
+			return std::dynamic_pointer_cast<T>(product);
 		}
-		return output_set;
 	}
 
-	// reference :181, src/register.cpp:14-24
+	// the product on input pin `key`, or nothing when the pin is not linked
+	template <typename T>
+	std::optional<std::reference_wrapper<T>> get_input_item(const Processor::Input_map& input, const std::string& key)
+	{
+		const auto it = input.find(key);
+		if (it == input.end()) return std::nullopt;
+		return std::ref(*detail::typed_product<T>(it->second, key, "input", true));
+	}
+
+	// every product hanging on output pin `key` (fan-out: one per outgoing link)
+	template <typename T>
+	std::set<std::shared_ptr<T>> get_output_item(const Processor::Output_map& output, const std::string& key)
+	{
+		const auto it = output.find(key);
+		if (it == output.end()) THROW_LOGIC_ERROR("Key '%s' not found in output map", key.c_str());
+		std::set<std::shared_ptr<T>> products;
+		for (const auto& product : it->second) products.insert(detail::typed_product<T>(product, key, "output", false));
+		return products;
+	}
+
 	void register_all_processors();
 }

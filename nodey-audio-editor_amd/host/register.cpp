@@ -1,6 +1,6 @@
-// register.cpp — mirror of /root/reference/src/register.cpp:14-24 for the nodes on the GPU path.
-// Audio_input / Audio_output (FFmpeg demux, SDL preview, LAME export) are codec/device I/O and stay the
-// reference's own; in the editor they remain registered from the reference's translation units.
+// register.cpp — fills Processor::processor_map with the GPU processors, under the identifiers of the CPU classes
+// they replace (reference list: src/register.cpp:16-23).  audio_input / audio_output are codec and device I/O and
+// stay the reference's own classes; audio_spectrum is new.
 #include "infra/processor.hpp"
 #include "processor/audio-mix.hpp"
 #include "processor/audio-velocity.hpp"
@@ -8,14 +8,18 @@
 
 namespace infra
 {
+	namespace
+	{
+		template <typename... Nodes>
+		void register_each()
+		{
+			(Processor::register_processor<Nodes>(), ...);
+		}
+	}
+
 	void register_all_processors()
 	{
-		Processor::register_processor<processor::Audio_vol>();
-		Processor::register_processor<processor::Velocity_modifier>();
-		Processor::register_processor<processor::Pitch_modifier>();
-		Processor::register_processor<processor::Audio_amix>();
-		Processor::register_processor<processor::Audio_bimix>();
-		Processor::register_processor<processor::Audio_bimix_v2>();
-		Processor::register_processor<processor::Audio_spectrum>();  // new node (no reference counterpart)
+		using namespace processor;
+		register_each<Audio_vol, Velocity_modifier, Pitch_modifier, Audio_amix, Audio_bimix, Audio_bimix_v2, Audio_spectrum>();
 	}
 }
