@@ -140,6 +140,7 @@ def main():
     mid_ratio = pl.mid_len / S
     alg_bytes = {                                        # per launch; DESIGN.md §4 derives each figure
         "amix_i2p_kernel": 24.0 * sf,                    # 2 x 8 B in + 8 B out            (mix n=2 = 24 B)
+        "mix_resample_tile_kernel": 24.0 * sf + 8.0 * sf * mid_ratio,   # the mix node's 24 B + the transposed signal once
         "pv_phase_kernel": 8.0 * sf,                     # re-read of the input (pass 1); output negligible
         "pv_scan_kernel": 0.0,
         "pv_synth_kernel": 8.0 * sf + 8.0 * sf * mid_ratio,   # input once + stretched signal once

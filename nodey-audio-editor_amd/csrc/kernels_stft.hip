@@ -731,6 +731,55 @@ constexpr int kRsMaxSpan = 4096 + 32;            // staged source samples per ch
 // kStereo && NS > 1: one workgroup produces the same output tile for NS streams.  The 16 interpolated coefficients
 // of an output depend on its position only, so they are built once (8 x 128-bit LDS reads, 48 instructions) and
 // applied to NS streams: the kernel is bound by LDS reads + VALU, and both drop by about a third at NS = 4.
+// outputs [j0, j1) of the tile for up to NS interleaved-stereo streams staged at stage + k * 2 * span_alloc: the 16
+// interpolated coefficients of an output are built once and applied to every stream
+template <int NS>
+__device__ __forceinline__ void rs_apply_stereo(const float* stab, const float* stage, int span_alloc, const RsParams& p, long long j0,
+                                                long long j1, long long m_lo, const OutViewD& out, long long s0, long long n_streams)
+{
+    const bool out_pair = (out.cs == 1) && (out.fs == 2) && ((out.ss & 1) == 0) && ((reinterpret_cast<uintptr_t>(out.base) & 7) == 0);
+    for (long long j = j0 + threadIdx.x; j < j1; j += 256) {
+        const unsigned long long lo = (unsigned long long)j * p.step_q32;
+        const unsigned long long hi = __umul64hi((unsigned long long)j, p.step_q32);
+        const long long idx = (long long)((hi << 32) | (lo >> 32));
+        const unsigned frac = (unsigned)lo;
+        const unsigned ph = frac >> 25;
+        const float alpha = (float)(frac & 0x1FFFFFFu) * (1.0f / 33554432.0f);
+        const float4* t0 = reinterpret_cast<const float4*>(stab + ph * kRsRow);
+        const float4* t1 = reinterpret_cast<const float4*>(stab + (ph + 1) * kRsRow);
+        float coef[NAE_RS_TAPS];
+#pragma unroll
+        for (int q = 0; q < NAE_RS_TAPS / 4; q++) {
+            const float4 a = t0[q], b = t1[q];
+            coef[4 * q + 0] = a.x + alpha * (b.x - a.x);
+            coef[4 * q + 1] = a.y + alpha * (b.y - a.y);
+            coef[4 * q + 2] = a.z + alpha * (b.z - a.z);
+            coef[4 * q + 3] = a.w + alpha * (b.w - a.w);
+        }
+        const int o = (int)(idx - (NAE_RS_TAPS / 2 - 1) - m_lo);
+#pragma unroll
+        for (int k = 0; k < NS; k++) {
+            if (s0 + k < n_streams) {
+                const float2* st = reinterpret_cast<const float2*>(stage + (size_t)k * 2 * span_alloc) + o;
+                float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+                for (int i = 0; i < NAE_RS_TAPS; i++) {
+                    const float2 x = st[i];
+                    a0 += coef[i] * x.x;
+                    a1 += coef[i] * x.y;
+                }
+                float* ob = out.base + (s0 + k) * out.ss;
+                if (out_pair) {
+                    *reinterpret_cast<float2*>(ob + 2 * j) = float2{a0, a1};
+                } else {
+                    ob[j * out.fs] = a0;
+                    ob[out.cs + j * out.fs] = a1;
+                }
+            }
+        }
+    }
+}
+
 template <bool kStereo, int NS>
 __global__ __launch_bounds__(256) void resample_tile_kernel(SigViewD src, RsParams p, const float* __restrict__ tab,
                                                            OutViewD out, int span_alloc, long long n_streams)
@@ -801,49 +850,22 @@ __global__ __launch_bounds__(256) void resample_tile_kernel(SigViewD src, RsPara
         }
     }
     __syncthreads();
-    const bool out_pair = kStereo && (out.cs == 1) && (out.fs == 2) && ((out.ss & 1) == 0) &&
-                          ((reinterpret_cast<uintptr_t>(out.base) & 7) == 0);
-    for (long long j = j0 + threadIdx.x; j < j1; j += 256) {
-        const unsigned long long lo = (unsigned long long)j * p.step_q32;
-        const unsigned long long hi = __umul64hi((unsigned long long)j, p.step_q32);
-        const long long idx = (long long)((hi << 32) | (lo >> 32));
-        const unsigned frac = (unsigned)lo;
-        const unsigned ph = frac >> 25;
-        const float alpha = (float)(frac & 0x1FFFFFFu) * (1.0f / 33554432.0f);
-        const float4* t0 = reinterpret_cast<const float4*>(stab + ph * kRsRow);
-        const float4* t1 = reinterpret_cast<const float4*>(stab + (ph + 1) * kRsRow);
-        float coef[NAE_RS_TAPS];
+    if (kStereo) {
+        rs_apply_stereo<NS>(stab, stage, span_alloc, p, j0, j1, m_lo, out, s0, n_streams);
+    } else {
+        for (long long j = j0 + threadIdx.x; j < j1; j += 256) {
+            const unsigned long long lo = (unsigned long long)j * p.step_q32;
+            const unsigned long long hi = __umul64hi((unsigned long long)j, p.step_q32);
+            const long long idx = (long long)((hi << 32) | (lo >> 32));
+            const unsigned frac = (unsigned)lo;
+            const unsigned ph = frac >> 25;
+            const float alpha = (float)(frac & 0x1FFFFFFu) * (1.0f / 33554432.0f);
+            const float* t0 = stab + ph * kRsRow;
+            const float* t1 = stab + (ph + 1) * kRsRow;
+            float coef[NAE_RS_TAPS];
 #pragma unroll
-        for (int q = 0; q < NAE_RS_TAPS / 4; q++) {
-            const float4 a = t0[q], b = t1[q];
-            coef[4 * q + 0] = a.x + alpha * (b.x - a.x);
-            coef[4 * q + 1] = a.y + alpha * (b.y - a.y);
-            coef[4 * q + 2] = a.z + alpha * (b.z - a.z);
-            coef[4 * q + 3] = a.w + alpha * (b.w - a.w);
-        }
-        const int o = (int)(idx - (NAE_RS_TAPS / 2 - 1) - m_lo);
-        if (kStereo) {
-#pragma unroll
-            for (int k = 0; k < NS; k++) {
-                if (s0 + k < n_streams) {
-                    const float2* st = reinterpret_cast<const float2*>(stage + (size_t)k * 2 * span_alloc) + o;
-                    float a0 = 0.0f, a1 = 0.0f;
-#pragma unroll
-                    for (int i = 0; i < NAE_RS_TAPS; i++) {
-                        const float2 x = st[i];
-                        a0 += coef[i] * x.x;
-                        a1 += coef[i] * x.y;
-                    }
-                    float* ob = out.base + (s0 + k) * out.ss;
-                    if (out_pair) {
-                        *reinterpret_cast<float2*>(ob + 2 * j) = float2{a0, a1};
-                    } else {
-                        ob[j * out.fs] = a0;
-                        ob[out.cs + j * out.fs] = a1;
-                    }
-                }
-            }
-        } else {
+            for (int i = 0; i < NAE_RS_TAPS; i++) coef[i] = t0[i] + alpha * (t1[i] - t0[i]);
+            const int o = (int)(idx - (NAE_RS_TAPS / 2 - 1) - m_lo);
             for (int c = 0; c < p.ch; c++) {
                 const float* st = stage + c * span_alloc + o;
                 float a = 0.0f;
@@ -853,6 +875,89 @@ __global__ __launch_bounds__(256) void resample_tile_kernel(SigViewD src, RsPara
             }
         }
     }
+}
+
+// mix(2) fused into the transposer's staging (graph: mix -> pitch with the transposer first).  The tile's source span
+// is mixed on the fly from the two interleaved inputs — out = (0 + a*va) + b*vb, the reference's order
+// (audio-amix.cpp:293-307) — written to the mix node's output for the frames this tile owns, and staged for the taps.
+// Saves the mix kernel's launch and one read of the mix buffer.
+struct MixFuseD {
+    const float* a; long long a_ss;       // interleaved stereo, 16-byte aligned
+    const float* b; long long b_ss;       // same; b_ss = 0: one buffer shared by every stream
+    float va, vb;
+    float* mix; long long mix_ss, mix_cs, mix_fs;
+};
+
+template <int NS>
+__global__ __launch_bounds__(256) void mix_resample_tile_kernel(MixFuseD f, RsParams p, const float* __restrict__ tab, OutViewD out,
+                                                               int span_alloc, long long n_streams)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char rs_smem[];
+    float* stab = reinterpret_cast<float*>(rs_smem);
+    float* stage = stab + (NAE_RS_PHASES + 1) * kRsRow;
+    for (int i = threadIdx.x; i < (NAE_RS_PHASES + 1) * NAE_RS_TAPS; i += 256)
+        stab[(i / NAE_RS_TAPS) * kRsRow + (i % NAE_RS_TAPS)] = tab[i];
+    const long long s0 = (long long)blockIdx.y * NS;
+    const long long j0 = (long long)blockIdx.x * kRsOut;
+    long long j1 = j0 + kRsOut;
+    const bool last = j1 >= p.out_len;
+    if (last) j1 = p.out_len;
+    auto idx_of = [&](long long j) {
+        const unsigned long long lo = (unsigned long long)j * p.step_q32, hi = __umul64hi((unsigned long long)j, p.step_q32);
+        return (long long)((hi << 32) | (lo >> 32));
+    };
+    const long long idx_first = idx_of(j0), idx_last = idx_of(j1 - 1);
+    const long long m_lo = (idx_first - (NAE_RS_TAPS / 2 - 1)) & ~3ll;
+    const long long m_hi = idx_last + NAE_RS_TAPS / 2 + 1;
+    // frames of the mix output this tile writes: from its first output's position to the next tile's
+    const long long own_lo = blockIdx.x == 0 ? 0 : idx_first;
+    const long long own_hi = last ? p.src_len : idx_of(j1);
+    const bool mix_planar = f.mix_fs == 1;
+    // two frames per thread and trip.  For every trip the loads of all NS streams are issued before anything is
+    // stored: the staging is latency-bound (one round trip to HBM per trip), so this cuts the trips by NS.
+    const long long m_end = last ? (p.src_len > m_hi ? p.src_len : m_hi) : m_hi;
+    for (long long m = m_lo + 2 * threadIdx.x; m < m_end; m += 2 * 256) {
+        float4 xa[NS], xb[NS];
+        const bool inside = m >= 0 && m + 2 <= p.src_len;
+#pragma unroll
+        for (int k = 0; k < NS; k++) {
+            xa[k] = xb[k] = float4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (s0 + k < n_streams) {
+                const float* __restrict__ a = f.a + (s0 + k) * f.a_ss;
+                const float* __restrict__ b = f.b + (s0 + k) * f.b_ss;
+                if (inside) {
+                    xa[k] = *reinterpret_cast<const float4*>(a + 2 * m);
+                    xb[k] = *reinterpret_cast<const float4*>(b + 2 * m);
+                } else {
+                    if (m >= 0 && m < p.src_len) { xa[k].x = a[2 * m]; xa[k].y = a[2 * m + 1]; xb[k].x = b[2 * m]; xb[k].y = b[2 * m + 1]; }
+                    if (m + 1 >= 0 && m + 1 < p.src_len) { xa[k].z = a[2 * m + 2]; xa[k].w = a[2 * m + 3]; xb[k].z = b[2 * m + 2]; xb[k].w = b[2 * m + 3]; }
+                }
+            }
+        }
+        const bool own0 = m >= own_lo && m < own_hi, own1 = m + 1 >= own_lo && m + 1 < own_hi;
+        const bool in0 = m >= 0 && m < p.src_len, in1 = m + 1 >= 0 && m + 1 < p.src_len;
+#pragma unroll
+        for (int k = 0; k < NS; k++) {
+            if (s0 + k < n_streams) {
+                float4 y;
+                y.x = in0 ? (0.0f + xa[k].x * f.va) + xb[k].x * f.vb : 0.0f;
+                y.y = in0 ? (0.0f + xa[k].y * f.va) + xb[k].y * f.vb : 0.0f;
+                y.z = in1 ? (0.0f + xa[k].z * f.va) + xb[k].z * f.vb : 0.0f;
+                y.w = in1 ? (0.0f + xa[k].w * f.va) + xb[k].w * f.vb : 0.0f;
+                if (m < m_hi) *reinterpret_cast<float4*>(stage + (size_t)k * 2 * span_alloc + 2 * (m - m_lo)) = y;   // (m_hi - m_lo) + 1 <= span_alloc
+                float* __restrict__ mx = f.mix + (s0 + k) * f.mix_ss;
+                if (own0 && own1 && mix_planar) {
+                    *reinterpret_cast<float2*>(mx + m) = float2{y.x, y.z};
+                    *reinterpret_cast<float2*>(mx + f.mix_cs + m) = float2{y.y, y.w};
+                } else {
+                    if (own0) { mx[m * f.mix_fs] = y.x; mx[f.mix_cs + m * f.mix_fs] = y.y; }
+                    if (own1) { mx[(m + 1) * f.mix_fs] = y.z; mx[f.mix_cs + (m + 1) * f.mix_fs] = y.w; }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    rs_apply_stereo<NS>(stab, stage, span_alloc, p, j0, j1, m_lo, out, s0, n_streams);
 }
 
 } // namespace nae
@@ -1036,6 +1141,44 @@ int nae_launch_resample(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig*
             NAE_KLAUNCH(ctx, "resample_kernel", resample_kernel, dim3(gx, (unsigned)ns), dim3(256), 0, ctx->stream, sv, p,
                         (long long)ns, d_tab, ov);
         int rc = nae_check(ctx, hipGetLastError(), "resample kernel");
+        if (rc) return rc;
+    }
+    return NAE_OK;
+}
+
+// mix(2) + transposer in one launch (see mix_resample_tile_kernel).  Returns 1 when the shapes do not fit the fused
+// kernel (the caller then runs the two nodes separately), 0 on success, < 0 on error.
+int nae_launch_mix_resample(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig* a, const nae_sig* b, float va, float vb,
+                            const nae_sig* mix_out, size_t S, size_t n_streams, const float* d_tab, const nae_sig* out)
+{
+    const double rho = (double)pl->step_q32 / 4294967296.0;
+    const long long span_need = (long long)(kRsOut * rho) + NAE_RS_TAPS + 8;
+    const int span_alloc = (int)((span_need + 3) & ~3ll);
+    auto inter16 = [](const nae_sig* v) {
+        return v->chan_stride == 1 && v->frame_stride == 2 && (reinterpret_cast<uintptr_t>(v->base) & 15) == 0 && (v->stream_stride & 3) == 0;
+    };
+    const bool mix_ok = (reinterpret_cast<uintptr_t>(mix_out->base) & 7) == 0 && (mix_out->stream_stride & 1) == 0 &&
+                        ((mix_out->frame_stride == 1 && (mix_out->chan_stride & 1) == 0) || mix_out->frame_stride >= 2);
+    if (ctx->dbg_no_mix_fuse || !inter16(a) || !inter16(b) || !mix_ok || span_need > kRsMaxSpan || span_alloc > 1536 || n_streams == 0 ||
+        pl->mid_len == 0 || S == 0)
+        return 1;
+    RsParams p{pl->step_q32, (long long)S, (long long)pl->mid_len, 2, 0};
+    const size_t lds = ((NAE_RS_PHASES + 1) * kRsRow + (size_t)2 * span_alloc * 4) * sizeof(float);
+    const unsigned gx = (unsigned)((pl->mid_len + kRsOut - 1) / kRsOut);
+    const size_t per_launch = (size_t)65535 * 4;
+    for (size_t s0 = 0; s0 < n_streams; s0 += per_launch) {
+        const size_t ns = (n_streams - s0 < per_launch) ? n_streams - s0 : per_launch;
+        MixFuseD f;
+        f.a = static_cast<const float*>(a->base) + s0 * a->stream_stride; f.a_ss = (long long)a->stream_stride;
+        f.b = static_cast<const float*>(b->base) + s0 * b->stream_stride; f.b_ss = (long long)b->stream_stride;
+        f.va = va; f.vb = vb;
+        f.mix = static_cast<float*>(mix_out->base) + s0 * mix_out->stream_stride;
+        f.mix_ss = (long long)mix_out->stream_stride; f.mix_cs = (long long)mix_out->chan_stride; f.mix_fs = (long long)mix_out->frame_stride;
+        OutViewD ov = to_out(out);
+        ov.base += (long long)s0 * ov.ss;
+        NAE_KLAUNCH(ctx, "mix_resample_tile_kernel", (mix_resample_tile_kernel<4>), dim3(gx, (unsigned)((ns + 3) / 4)), dim3(256), lds,
+                    ctx->stream, f, p, d_tab, ov, span_alloc, (long long)ns);
+        int rc = nae_check(ctx, hipGetLastError(), "mix_resample_tile_kernel");
         if (rc) return rc;
     }
     return NAE_OK;

@@ -187,6 +187,7 @@ int nae_ctx_create(int device, nae_ctx** out)
     ctx->dbg_pv_lowocc = getenv("NAE_PV_LOWOCC") != nullptr;
     ctx->dbg_pv_no_pipeline = getenv("NAE_PV_NO_PIPELINE") != nullptr;
     ctx->dbg_rs_single = getenv("NAE_RS_SINGLE") != nullptr;
+    ctx->dbg_no_mix_fuse = getenv("NAE_NO_MIX_FUSE") != nullptr;
     if (const char* e = getenv("NAE_TD_NC")) ctx->dbg_td_nc = atoi(e);
     ctx->dbg_pv_lockstep = 8;
     if (const char* e = getenv("NAE_PV_LOCKSTEP")) {
@@ -396,8 +397,17 @@ static int check_sig(nae_ctx* ctx, const nae_sig* s, const char* what)
     return NAE_OK;
 }
 
-int nae_stretch_block_f32(nae_ctx* ctx, double rate, double pitch, const nae_sig* src, size_t in_len, int ch,
-                          size_t n_streams, const nae_sig* dst)
+} // extern "C"
+
+// a 2-input mix node in front of the stretch node (graph4): when the transposer runs first it can mix while staging
+struct nae_mix_front {
+    const nae_sig* a;
+    const nae_sig* b;
+    float va, vb;
+};
+
+static int stretch_block_impl(nae_ctx* ctx, double rate, double pitch, const nae_sig* src, size_t in_len, int ch, size_t n_streams,
+                              const nae_sig* dst, const nae_mix_front* front)
 {
     if (!ctx) return NAE_ERR_INVALID;
     int rc;
@@ -406,8 +416,20 @@ int nae_stretch_block_f32(nae_ctx* ctx, double rate, double pitch, const nae_sig
     nae_stretch_plan pl;
     rc = nae_stretch_plan_make(rate, pitch, in_len, &pl);
     if (rc) return nae_fail(ctx, rc, "rate/pitch outside the supported range");
-    if (n_streams == 0 || pl.out_len == 0) return NAE_OK;
-    if (!pl.pv_on && !pl.rs_on) return nae_launch_copy_sig(ctx, src, dst, in_len, ch, n_streams, false, 1.0f);
+    // the mix node in front: fused into the transposer when that runs first, else its own launch (src = its output)
+    bool mix_pending = front != nullptr;
+    auto run_mix = [&]() -> int {
+        if (!mix_pending) return NAE_OK;
+        mix_pending = false;
+        const nae_sig ins[2] = {*front->a, *front->b};
+        const float vol[2] = {front->va, front->vb};
+        return nae_amix_sig_f32(ctx, ins, vol, 2, src, in_len, n_streams);
+    };
+    if (n_streams == 0 || pl.out_len == 0) return run_mix();
+    if (!pl.pv_on && !pl.rs_on) {
+        if ((rc = run_mix())) return rc;
+        return nae_launch_copy_sig(ctx, src, dst, in_len, ch, n_streams, false, 1.0f);
+    }
 
     const size_t mid_stride = (pl.mid_len + 3) & ~(size_t)3;
     nae_sig mid{};
@@ -426,14 +448,24 @@ int nae_stretch_block_f32(nae_ctx* ctx, double rate, double pitch, const nae_sig
     const nae_sig* pv_dst = dst;
     long long pv_out_len = (long long)pl.out_len;
     if (pl.rs_first) {
-        rc = nae_launch_resample(ctx, &pl, src, in_len, ch, n_streams, ctx->d_rs_tab, &mid, 0, pl.mid_len);
-        if (rc) return rc;
+        rc = 1;
+        if (mix_pending && ch == 2) {
+            rc = nae_launch_mix_resample(ctx, &pl, front->a, front->b, front->va, front->vb, src, in_len, n_streams, ctx->d_rs_tab, &mid);
+            if (rc < 0) return rc;
+            if (rc == 0) mix_pending = false;
+        }
+        if (rc == 1) {
+            if ((rc = run_mix())) return rc;
+            rc = nae_launch_resample(ctx, &pl, src, in_len, ch, n_streams, ctx->d_rs_tab, &mid, 0, pl.mid_len);
+            if (rc) return rc;
+        }
         pv_src = &mid;
         pv_in_len = pl.mid_len;
     } else if (pl.pv_on && pl.rs_on) {
         pv_dst = &mid;
         pv_out_len = (long long)pl.mid_len;
     }
+    if ((rc = run_mix())) return rc;     // vocoder first / transposer only: the mix is a launch of its own
     if (pl.pv_on) {
         const int tile = nae_pick_pv_tile(ctx, pl.frames, n_streams * ch);
         rc = nae_ws_reserve(ctx, &ctx->ws_phase, &ctx->ws_phase_bytes, nae_pv_phase_workspace_bytes(pl.frames, ch, n_streams, tile));
@@ -451,6 +483,14 @@ int nae_stretch_block_f32(nae_ctx* ctx, double rate, double pitch, const nae_sig
         if (rc) return rc;
     }
     return NAE_OK;
+}
+
+extern "C" {
+
+int nae_stretch_block_f32(nae_ctx* ctx, double rate, double pitch, const nae_sig* src, size_t in_len, int ch,
+                          size_t n_streams, const nae_sig* dst)
+{
+    return stretch_block_impl(ctx, rate, pitch, src, in_len, ch, n_streams, dst, nullptr);
 }
 
 int nae_debug_pv_tile_phase(nae_ctx* ctx, double rate, double pitch, const nae_sig* src, size_t in_len, int ch,
@@ -518,12 +558,11 @@ int nae_graph4_run(nae_ctx* ctx, const nae_graph4* g)
 {
     if (!ctx || !g) return NAE_ERR_INVALID;
     // node 1+2: the two inputs feed the 2-input mixer (audio-amix.cpp:86-324 with input_num = 2)
-    const nae_sig ins[2] = {g->in_a, g->in_b};
-    const float vol[2] = {g->vol_a, g->vol_b};
-    int rc = nae_amix_sig_f32(ctx, ins, vol, 2, &g->mix_out, g->S, g->n_streams);
-    if (rc) return rc;
-    // node 3: pitch (audio-velocity.cpp:462-477)
-    rc = nae_stretch_block_f32(ctx, g->rate, g->pitch, &g->mix_out, g->S, 2, g->n_streams, &g->pitch_out);
+    // node 3: pitch (audio-velocity.cpp:462-477).  When its transposer runs first the mix happens inside that launch
+    // (same arithmetic, same mix_out contents); otherwise the mix is launched on its own in front.
+    if (!g->in_a.base || !g->in_b.base || !g->mix_out.base) return nae_fail(ctx, NAE_ERR_INVALID, "nae_graph4_run: null signal");
+    const nae_mix_front front{&g->in_a, &g->in_b, g->vol_a, g->vol_b};
+    int rc = stretch_block_impl(ctx, g->rate, g->pitch, &g->mix_out, g->S, 2, g->n_streams, &g->pitch_out, &front);
     if (rc) return rc;
     nae_stretch_plan pl;
     rc = nae_stretch_plan_make(g->rate, g->pitch, g->S, &pl);

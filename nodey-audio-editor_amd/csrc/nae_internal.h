@@ -31,6 +31,7 @@ struct nae_ctx {
     int dbg_pv_lockstep = 8;         // NAE_PV_LOCKSTEP=N: workgroup barrier every N frames in the pipelined synth kernel (0: never)
     int dbg_td_nc = 0;               // NAE_TD_NC=1|2|4: candidates per thread of the WSOLA search (0: by batch size)
     bool dbg_pv_no_pipeline = false; // NAE_PV_NO_PIPELINE: use the non-pipelined synth kernel for long tiles
+    bool dbg_no_mix_fuse = false;    // NAE_NO_MIX_FUSE: graph4 runs mix and transposer as separate launches
     bool dbg_rs_single = false;      // NAE_RS_SINGLE: one stream per transposer workgroup (no coefficient sharing)
     bool dbg_rs_direct = false;      // NAE_RS_DIRECT: direct (unstaged) transposer kernel
     bool dbg_spec_generic = false;   // NAE_SPEC_GENERIC: skip the interleaved-stereo spectrum fast path
@@ -80,6 +81,8 @@ int nae_launch_pv_synth(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig*
                         const nae_pv_segment* seg);
 int nae_launch_resample(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig* src, size_t src_len, int ch,
                         size_t n_streams, const float* d_tab, const nae_sig* out, size_t j_begin, size_t j_end);
+int nae_launch_mix_resample(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig* a, const nae_sig* b, float va, float vb,
+                            const nae_sig* mix_out, size_t S, size_t n_streams, const float* d_tab, const nae_sig* out);
 int nae_ensure_rs_table(nae_ctx* ctx, double rate_eff);
 int nae_pick_pv_tile(nae_ctx* ctx, size_t frames, size_t n_sc);
 constexpr int kPhasePad = 520; // int32 per (stream-channel, tile) record in the phase workspace

@@ -191,22 +191,29 @@ def test_k7_full_size_properties(ctx, nae):
     assert rel_rms(got[: 2 * 96000], ref[: 2 * 96000]) <= TOL
 
 
-def test_graph4_matches_node_by_node_oracle(ctx, nae):
-    """input -> mix(2) -> pitch -> spectrum on 3 streams with a shared second input"""
-    n_streams, S = 3, 20000
+@pytest.mark.parametrize("n_streams,S,semis,rate,shared_b,planar_mix,vols", [
+    (3, 20000, 3, 1.0, True, True, (0.5, 0.5)),        # transposer first: the mix is fused into its staging
+    (6, 8193, 5, 1.0, False, True, (0.3, 0.9)),        # one full group of 4 streams + a partial one, odd length
+    (5, 3000, 3, 1.0, True, False, (1.0, 0.25)),       # interleaved mix output; shorter than 3 transposer tiles
+    (2, 20000, -4, 1.0, True, True, (0.5, 0.5)),       # vocoder first: the mix stays a launch of its own
+    (2, 12000, 0, 1.5, True, True, (0.5, 0.5)),        # plain rate change (transposer only)
+    (1, 6000, 0, 1.0, True, True, (0.5, 0.5)),         # identity pitch node
+])
+def test_graph4_matches_node_by_node_oracle(ctx, nae, n_streams, S, semis, rate, shared_b, planar_mix, vols):
+    """input -> mix(2) -> pitch -> spectrum: every node's output against the oracle run node by node"""
     a = orc.fill_uniform(n_streams * S * 2, 51)
-    b = orc.fill_uniform(S * 2, 52)
-    p = 2 ** (3 / 12)
-    pl = ctx.stretch_plan(1.0, p, S)
+    b = orc.fill_uniform((1 if shared_b else n_streams) * S * 2, 52)
+    p = 2 ** (semis / 12)
+    pl = ctx.stretch_plan(rate, p, S)
     F = ctx.spectrum_frames(pl.out_len)
     d_a, d_b = ctx.array(a), ctx.array(b)
-    d_mix, d_pitch, d_spec = ctx.empty(n_streams * S * 2), ctx.empty(n_streams * pl.out_len * 2), ctx.empty(n_streams * F * 2 * 513)
+    d_mix, d_pitch, d_spec = ctx.empty(n_streams * S * 2), ctx.empty(max(1, n_streams * pl.out_len * 2)), ctx.empty(max(1, n_streams * F * 2 * 513))
     g = nae.Graph4()
     g.in_a = nae.Sig.interleaved(d_a.ptr, S, 2)
-    g.in_b = nae.Sig.interleaved(d_b.ptr, S, 2, shared=True)
-    g.vol_a, g.vol_b = 0.5, 0.5
-    g.mix_out = nae.Sig.planar(d_mix.ptr, S, 2)
-    g.rate, g.pitch = 1.0, p
+    g.in_b = nae.Sig.interleaved(d_b.ptr, S, 2, shared=shared_b)
+    g.vol_a, g.vol_b = vols
+    g.mix_out = nae.Sig.planar(d_mix.ptr, S, 2) if planar_mix else nae.Sig.interleaved(d_mix.ptr, S, 2)
+    g.rate, g.pitch = rate, p
     g.pitch_out = nae.Sig.interleaved(d_pitch.ptr, pl.out_len, 2)
     g.spec_out, g.spec_stream_stride = d_spec.ptr, F * 2 * 513
     g.S, g.n_streams = S, n_streams
@@ -214,15 +221,18 @@ def test_graph4_matches_node_by_node_oracle(ctx, nae):
     mix, pitch, spec = d_mix.download(), d_pitch.download(), d_spec.download()
     for s in range(n_streams):
         xs = a.reshape(n_streams, S, 2)[s]
-        L, R = orc.amix([xs[:, 0], b[0::2]], [xs[:, 1], b[1::2]], [0.5, 0.5])
-        m = mix.reshape(n_streams, 2, S)[s]
-        assert np.array_equal(m[0], L) and np.array_equal(m[1], R)                         # mix: bit-exact
-        ref_p = orc.stretch(np.stack([L, R], 1).reshape(-1), 2, 1.0, p)
-        got_p = pitch.reshape(n_streams, -1)[s]
+        bs = b.reshape(-1, S, 2)[0 if shared_b else s]
+        L, R = orc.amix([xs[:, 0], bs[:, 0]], [xs[:, 1], bs[:, 1]], list(vols))
+        m = mix.reshape(n_streams, 2, S)[s] if planar_mix else mix.reshape(n_streams, S, 2)[s].T
+        assert np.array_equal(m[0], L) and np.array_equal(m[1], R), s                      # mix: bit-exact
+        ref_p = orc.stretch(np.stack([L, R], 1).reshape(-1), 2, rate, p)
+        got_p = pitch[: n_streams * pl.out_len * 2].reshape(n_streams, -1)[s]
         assert rel_rms(got_p, ref_p) <= TOL                                                # pitch: tolerance
-        ref_s = orc.spectrum(got_p, 2)                                                     # spectrum of what the GPU fed it
-        assert np.array_equal(spec.reshape(n_streams, F, 2, 513)[s].view(np.uint32), ref_s.view(np.uint32))
-        assert rel_rms(spec.reshape(n_streams, F, 2, 513)[s], orc.spectrum(ref_p, 2)) <= TOL  # end to end
+        if F:
+            got_s = spec[: n_streams * F * 2 * 513].reshape(n_streams, F, 2, 513)[s]
+            ref_s = orc.spectrum(got_p, 2)                                                 # spectrum of what the GPU fed it
+            assert np.array_equal(got_s.view(np.uint32), ref_s.view(np.uint32))
+            assert rel_rms(got_s, orc.spectrum(ref_p, 2)) <= TOL                           # end to end
     for d in (d_a, d_b, d_mix, d_pitch, d_spec):
         d.free()
 
