@@ -599,8 +599,10 @@ __global__ __launch_bounds__(kThreads, 2) void pv_synth2_kernel(SigViewD src, Pv
 #pragma unroll
         for (int j = 0; j < 8; j++) va[j] = cf{nxt[j].x * win[j].x, nxt[j].y * win[j].y};
         if (f + 1 < f_end) load_frame_raw<kUnit>(nxt, in, frame_start(p, f + 1), lane);
+#ifndef NAE_ABL_NO_FFT
         if (have) fft512_fwd2(va, zs, SA, SS, tw, lane);
         else fft512_fwd<false>(va, SA, tw, lane);
+#endif
         // ---- phase P1: split exchange (write Z) | overlap-add of frame fz
 #pragma unroll
         for (int r = 0; r < 8; r++) SA[lane + 64 * r] = va[r];
@@ -647,9 +649,13 @@ __global__ __launch_bounds__(kThreads, 2) void pv_synth2_kernel(SigViewD src, Pv
         if (have) {
 #pragma unroll
             for (int r = 0; r < 8; r++) {
+#ifdef NAE_ABL_NO_ROTATE
+                cf y{va[r].x + __uint_as_float(qs[r] - qa[r]), va[r].y};
+#else
                 const float ph = (float)(int32_t)(qs[r] - qa[r]) * (1.0f / 4294967296.0f);
                 const float cs = __builtin_amdgcn_cosf(ph), sn = __builtin_amdgcn_sinf(ph);
                 cf y{__builtin_fmaf(va[r].x, cs, -(va[r].y * sn)), __builtin_fmaf(va[r].x, sn, va[r].y * cs)};
+#endif
                 if (r == 0 && lane == 0) y.y = 0.0f;
                 SA[lane + 64 * r] = y;
             }

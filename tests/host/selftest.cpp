@@ -5,6 +5,7 @@
 #include "infra/runner.hpp"
 #include "processor/audio-mix.hpp"
 #include "processor/audio-velocity.hpp"
+#include "processor/gpu-context.hpp"
 #include "processor/audio-vol.hpp"
 #include "../../oracle/nae_oracle.h"
 
@@ -238,10 +239,28 @@ static void test_gpu_volume()
 		r.add_node(3, sink);
 		r.add_link({1, "output", 2, "input"});
 		r.add_link({2, "output", 3, "input"});
+		nae_ctx* gctx = processor::gpu::context();
+		nae_prof_reset(gctx);
+		nae_prof_enable(gctx, 1);
 		const bool ok = r.run();
+		nae_prof_enable(gctx, 0);
 		CHECK(ok, "volume graph runs (format " << format << "): " << r.get_processor_resources().at(2)->error_text);
 		if (!ok) continue;
 		CHECK(sink->frames.size() == (20000 + 1151) / 1152, "frame count preserved");
+		{
+			// batching: frames already queued behind the first share its launch
+			uint64_t launches = 0;
+			const int n = nae_prof_get(gctx, -1, nullptr, 0, nullptr, nullptr);
+			for (int k = 0; k < n; k++)
+			{
+				char name[128];
+				double ms = 0;
+				uint64_t cnt = 0;
+				nae_prof_get(gctx, k, name, sizeof name, &ms, &cnt);
+				launches += cnt;
+			}
+			CHECK(launches >= 1 && launches < sink->frames.size(), "volume node batches queued frames: " << launches << " launches for " << sink->frames.size() << " frames");
+		}
 		size_t pos = 0;
 		bool same = true;
 		for (auto& f : sink->frames)
