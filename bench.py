@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--cpu-streams", type=int, default=128, help="streams the CPU-oracle baseline is timed on")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--semitones", type=float, default=SEMITONES, help="pitch node setting (headline: +3)")
+    ap.add_argument("--rate", type=float, default=1.0, help="SoundTouch setRate of the pitch node (headline: 1)")
     ap.add_argument("--no-alt", action="store_true", help="skip the side measurement of the SoundTouch-shaped pitch node")
     return ap.parse_args()
 
@@ -64,8 +66,8 @@ def main():
     from nodey_audio_editor_amd import shard
     ctx = nae.Context(local_rank)
     n_streams, S = a.streams, int(round(a.seconds * 48000))
-    pitch = 2.0 ** (SEMITONES / 12.0)
-    pl = ctx.stretch_plan(1.0, pitch, S)
+    pitch = 2.0 ** (a.semitones / 12.0)
+    pl = ctx.stretch_plan(a.rate, pitch, S)
     F = ctx.spectrum_frames(pl.out_len)
 
     # ---- buffers (all HBM-resident before timing)
@@ -95,7 +97,7 @@ def main():
     g.in_b = nae.Sig.interleaved(b_ptr, S, 2, shared=True)
     g.vol_a = g.vol_b = 0.5
     g.mix_out = nae.Sig.planar(d_mix.ptr, S, 2)
-    g.rate, g.pitch = 1.0, pitch
+    g.rate, g.pitch = a.rate, pitch
     g.pitch_out = nae.Sig.interleaved(d_pitch.ptr, pl.out_len, 2)
     g.spec_out, g.spec_stream_stride = d_spec.ptr, F * 2 * BINS
     g.S, g.n_streams = S, n_streams
@@ -176,7 +178,8 @@ def main():
         "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "C5 (BASELINE.json configs[4]): independent 48 kHz stereo f32 streams through "
-                               "input->mix(2)->pitch(+3 semitones, phase vocoder N=1024 hop=256)->spectrum(N=1024 hop=256)",
+                               f"input->mix(2)->pitch({a.semitones:+g} semitones, rate {a.rate:g}, phase vocoder N=1024 hop=256)"
+                               "->spectrum(N=1024 hop=256)",
                    "streams_per_gpu": n_streams, "seconds_per_stream": a.seconds, "sample_frames_per_stream": S,
                    "shared_second_input": True, "parallelism": f"streams sharded over {world} GPU(s), no data-path collective",
                    "device": ctx.name()},
@@ -189,16 +192,16 @@ def main():
     # ---- the same pitch node with the SoundTouch-shaped WSOLA chain (K7 option A) instead of the phase vocoder:
     # reported beside the headline, never part of `value`
     if not a.no_alt and world == 1:
-        wpl = ctx.wsola_plan(48000, 2, 1.0, pitch, S)
+        wpl = ctx.wsola_plan(48000, 2, a.rate, pitch, S)
         wdst = nae.Sig.interleaved(d_pitch.ptr, wpl.out_len, 2)
         assert wpl.out_len <= pl.out_len
-        ctx.wsola_block(48000, 1.0, pitch, g.mix_out, S, 2, n_streams, wdst)     # plan, table, workspaces
+        ctx.wsola_block(48000, a.rate, pitch, g.mix_out, S, 2, n_streams, wdst)     # plan, table, workspaces
         ctx.sync()
         ctx.prof_reset()
         ctx.prof_enable(True)
         tw0 = time.perf_counter()
         for _ in range(2):
-            ctx.wsola_block(48000, 1.0, pitch, g.mix_out, S, 2, n_streams, wdst)
+            ctx.wsola_block(48000, a.rate, pitch, g.mix_out, S, 2, n_streams, wdst)
         ctx.sync()
         w_ms = (time.perf_counter() - tw0) / 2 * 1e3
         ctx.prof_enable(False)
@@ -224,7 +227,7 @@ def main():
         for s in range(k):
             x = ins[s]
             L, R = orc.amix([x[0::2], b[0::2]], [x[1::2], b[1::2]], [0.5, 0.5])
-            p_out = orc.stretch(orc.interleave([L, R]), 2, 1.0, pitch)
+            p_out = orc.stretch(orc.interleave([L, R]), 2, a.rate, pitch)
             sp = orc.spectrum(p_out, 2)
             if s == 0:
                 refs = [p_out, sp]
