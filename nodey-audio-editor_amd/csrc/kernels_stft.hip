@@ -606,7 +606,9 @@ __global__ __launch_bounds__(kThreads, 2) void pv_synth2_kernel(SigViewD src, Pv
         // ---- phase P1: split exchange (write Z) | overlap-add of frame fz
 #pragma unroll
         for (int r = 0; r < 8; r++) SA[lane + 64 * r] = va[r];
+#ifndef NAE_ABL_NO_OLA
         if (have) ola(zs, fz);
+#endif
         wave_lds_sync();
         // ---- phase P2: split (mirror read) -> X | store the completed block of frame fz
         cf nyq;
@@ -621,13 +623,21 @@ __global__ __launch_bounds__(kThreads, 2) void pv_synth2_kernel(SigViewD src, Pv
         for (int r = 0; r < 8; r++) {
             const int k = lane + 64 * r;
             const cf A = va[r];
+#ifdef NAE_ABL_NO_SPLIT
+            const cf B = cf{A.y, A.x};
+#else
             const cf B = SA[(512 - k) & 511];
+#endif
             const cf E = cf{0.5f * (A.x + B.x), 0.5f * (A.y - B.y)};
             const cf O = cf{0.5f * (A.x - B.x), 0.5f * (A.y + B.y)};
             const cf P = cmul_tw(O, tsp[r]);
             va[r] = cf{E.x + P.y, E.y - P.x};
         }
+#ifndef NAE_ABL_NO_OLA
         if (have) emit(fz);
+#else
+        if (have && fz == f_end - 2) { ola(zs, fz); emit(fz); }
+#endif
         wave_lds_sync();
         // ---- phase P3: phases, integer phase advance, rotation -> Y (natural order in SA)
         uint32_t qa[9];
@@ -669,7 +679,11 @@ __global__ __launch_bounds__(kThreads, 2) void pv_synth2_kernel(SigViewD src, Pv
 #pragma unroll
             for (int r = 0; r < 8; r++) {
                 const int k = lane + 64 * r;
+#ifdef NAE_ABL_NO_UNSPLIT
+                const cf Xk = va[r], Xm = cf{va[r].y, va[r].x};
+#else
                 const cf Xk = SA[k], Xm = SA[512 - k];
+#endif
                 const cf T = tsp[r];
                 const cf E{Xk.x + Xm.x, Xk.y - Xm.y};       // 2E, 2D: the factor 1/2 lives in wsy
                 const cf D{Xk.x - Xm.x, Xk.y + Xm.y};
