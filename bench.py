@@ -237,6 +237,23 @@ def main():
                                          f"oracle C restatement (-O3, no fast-math), 1 thread as the reference's runner "
                                          f"is single-threaded (src/infra/runner.cpp:65-69); host has {os.cpu_count()} cpus",
                                "seconds": round(tc1 - tc0, 2)}
+        # the same restatement on the box's CPU share, one stream per worker thread (a fair upper bound
+        # for a CPU implementation; the reference itself runs every node on ONE thread).  ctypes drops the GIL in C.
+        from concurrent.futures import ThreadPoolExecutor
+        workers = max(1, min(16, os.cpu_count() or 1))
+
+        def one(x):
+            L, R = orc.amix([x[0::2], b[0::2]], [x[1::2], b[1::2]], [0.5, 0.5])
+            orc.spectrum(orc.stretch(orc.interleave([L, R]), 2, a.rate, pitch), 2)
+
+        reps = max(1, (2 * workers + k - 1) // k)
+        with ThreadPoolExecutor(workers) as ex:
+            list(ex.map(one, ins[:workers]))              # untimed: the first concurrent pass runs serially (arena set-up)
+            tm0 = time.perf_counter()
+            list(ex.map(one, ins * reps))
+            tm1 = time.perf_counter()
+        out["cpu_baseline"]["all_workers"] = {"value": k * reps * S / (tm1 - tm0), "unit": "sample-frames/s", "cores": workers,
+                                              "sample": f"{k * reps} stream-runs over {workers} threads", "seconds": round(tm1 - tm0, 2)}
         # parity of this very run: stream 0 of the GPU result against the oracle
         gp = np.empty(pl.out_len * 2, np.float32)
         gs = np.empty(F * 2 * BINS, np.float32)
