@@ -487,7 +487,7 @@ __global__ __launch_bounds__(kThreads, kOcc) void pv_synth_kernel(SigViewD src, 
 // iteration f runs the ANALYSIS FFT of frame f and the INVERSE FFT of frame f-1 in lockstep (fft512_fwd2), then
 // overlaps frame f's split / phase / rotation / c2r pre-twiddle with frame f-1's overlap-add and block store.
 // Same arithmetic, same summation order, 8 wave syncs per frame instead of 14.
-constexpr size_t kLdsPerWavePv2 = 2 * kScratchCf * sizeof(cf) + kRingFloats * sizeof(float);
+constexpr size_t kLdsPerWavePv2 = 2 * kScratchCf * sizeof(cf);     // two FFT scratch areas; the overlap-add ring is in registers
 
 template <bool kUnit>
 __global__ __launch_bounds__(kThreads, 2) void pv_synth2_kernel(SigViewD src, PvParams p, long long n_items,
@@ -505,7 +505,6 @@ __global__ __launch_bounds__(kThreads, 2) void pv_synth2_kernel(SigViewD src, Pv
     unsigned char* wave_base = smem2 + kLdsTables + wave_id() * kLdsPerWavePv2;
     cf* SA = reinterpret_cast<cf*>(wave_base);
     cf* SS = SA + kScratchCf;
-    float* ring = reinterpret_cast<float*>(SS + kScratchCf);
 
     const int lane = threadIdx.x & 63;
     const long long item = (long long)blockIdx.x * kWaves + wave_id();
@@ -547,42 +546,44 @@ __global__ __launch_bounds__(kThreads, 2) void pv_synth2_kernel(SigViewD src, Pv
     }
     const cf tsp_nyq = t1024[512];
 
-    // overlap-add of one synthesised frame (z = conj(time samples) * 512 in natural pair order) into the ring
-    auto ola = [&](const cf (&z)[8], long long fz) {
+    // Overlap-add in registers.  Sample n = 2*(lane + 64 r) + {0,1} of a frame falls into hop block r >> 1 at offset
+    // 2*lane + 128*(r & 1) + {0,1}: a lane touches the same 4 offsets of every block, so the 3 open blocks are 12 VGPRs
+    // (the 4th block a frame touches is new).  Block fz-3 is complete once frame fz is in; contributions arrive in
+    // increasing frame order, as in the oracle.  (The LDS ring this replaces cost 14 LDS instructions per frame.)
+    float r0[4] = {0.0f, 0.0f, 0.0f, 0.0f}, r1[4] = {0.0f, 0.0f, 0.0f, 0.0f}, r2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    auto ola_emit = [&](const cf (&z)[8], long long fz) {
+        float y[4][4];
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-            const int n2 = 2 * (lane + 64 * r);
-            const float y0 = z[r].x * wsy[r].x;
-            const float y1 = z[r].y * wsy[r].y;
-            const int blk = (int)((fz - 3 + (r >> 1)) & 3);
-            float2* slot = reinterpret_cast<float2*>(ring + blk * NAE_HOP + (n2 & (NAE_HOP - 1)));
-            if ((r >> 1) == 3) {
-                *slot = float2{y0, y1};
-            } else {
-                float2 a = *slot;
-                a.x += y0; a.y += y1;
-                *slot = a;
-            }
+            y[r >> 1][2 * (r & 1)] = z[r].x * wsy[r].x;
+            y[r >> 1][2 * (r & 1) + 1] = z[r].y * wsy[r].y;
         }
-    };
-    // store hop block fz-3 once frame fz has been added
-    auto emit = [&](long long fz) {
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            o[i] = r0[i] + y[0][i];
+            r0[i] = r1[i] + y[1][i];
+            r1[i] = r2[i] + y[2][i];
+            r2[i] = y[3][i];
+        }
         const long long be = fz - 3;                         // wave-uniform: block base and pointer stay scalar
         if (be >= b0 && be < b_end && be * NAE_HOP < p.mid_len) {
-            const float4 a = *reinterpret_cast<const float4*>(ring + (int)(be & 3) * NAE_HOP + 4 * lane);
             float* pb = optr + be * NAE_HOP * out.fs;
+            const int fs = (int)out.fs;
             if ((be + 1) * NAE_HOP <= p.mid_len) {
-                if (out_vec) *reinterpret_cast<float4*>(pb + 4 * lane) = a;
-                else {
-                    const int fs = (int)out.fs, o = 4 * lane * fs;
-                    pb[o] = a.x; pb[o + fs] = a.y; pb[o + 2 * fs] = a.z; pb[o + 3 * fs] = a.w;
+                if (out_vec) {
+                    *reinterpret_cast<float2*>(pb + 2 * lane) = float2{o[0], o[1]};
+                    *reinterpret_cast<float2*>(pb + 128 + 2 * lane) = float2{o[2], o[3]};
+                } else {
+                    const int a = 2 * lane * fs, b = (128 + 2 * lane) * fs;
+                    pb[a] = o[0]; pb[a + fs] = o[1]; pb[b] = o[2]; pb[b + fs] = o[3];
                 }
             } else {
-                const int rem = (int)(p.mid_len - be * NAE_HOP), fs = (int)out.fs, o = 4 * lane * fs;
-                if (4 * lane + 0 < rem) pb[o] = a.x;
-                if (4 * lane + 1 < rem) pb[o + fs] = a.y;
-                if (4 * lane + 2 < rem) pb[o + 2 * fs] = a.z;
-                if (4 * lane + 3 < rem) pb[o + 3 * fs] = a.w;
+                const int rem = (int)(p.mid_len - be * NAE_HOP);
+                if (2 * lane + 0 < rem) pb[(2 * lane) * fs] = o[0];
+                if (2 * lane + 1 < rem) pb[(2 * lane + 1) * fs] = o[1];
+                if (128 + 2 * lane < rem) pb[(128 + 2 * lane) * fs] = o[2];
+                if (129 + 2 * lane < rem) pb[(129 + 2 * lane) * fs] = o[3];
             }
         }
     };
@@ -606,9 +607,6 @@ __global__ __launch_bounds__(kThreads, 2) void pv_synth2_kernel(SigViewD src, Pv
         // ---- phase P1: split exchange (write Z) | overlap-add of frame fz
 #pragma unroll
         for (int r = 0; r < 8; r++) SA[lane + 64 * r] = va[r];
-#ifndef NAE_ABL_NO_OLA
-        if (have) ola(zs, fz);
-#endif
         wave_lds_sync();
         // ---- phase P2: split (mirror read) -> X | store the completed block of frame fz
         cf nyq;
@@ -634,9 +632,9 @@ __global__ __launch_bounds__(kThreads, 2) void pv_synth2_kernel(SigViewD src, Pv
             va[r] = cf{E.x + P.y, E.y - P.x};
         }
 #ifndef NAE_ABL_NO_OLA
-        if (have) emit(fz);
+        if (have) ola_emit(zs, fz);
 #else
-        if (have && fz == f_end - 2) { ola(zs, fz); emit(fz); }
+        if (have && fz == f_end - 2) ola_emit(zs, fz);
 #endif
         wave_lds_sync();
         // ---- phase P3: phases, integer phase advance, rotation -> Y (natural order in SA)
@@ -696,9 +694,7 @@ __global__ __launch_bounds__(kThreads, 2) void pv_synth2_kernel(SigViewD src, Pv
     }
     if (have) {   // drain the last synthesised frame
         fft512_fwd<false>(zs, SS, tw, lane);
-        ola(zs, fz);
-        wave_lds_sync();
-        emit(fz);
+        ola_emit(zs, fz);
     }
 }
 
