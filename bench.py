@@ -50,6 +50,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     torch = None
+    # stdout carries exactly ONE line, the JSON result: until that line is printed, file descriptor 1 points at stderr
+    # (RCCL writes a version banner to stdout when its first communicator is created)
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import naeload
     if world > 1 or a.gpus > 1 or os.environ.get("NAE_FORCE_DIST"):
         # torch first: its bundled libamdhip64.so.7 is then the one HIP runtime of the process (same soname as
@@ -262,8 +267,11 @@ def main():
         ctx.sync()
         rr = lambda x, y: float(np.sqrt(np.mean((x.astype(np.float64) - y) ** 2)) / np.sqrt(np.mean(y.astype(np.float64) ** 2)))
         out["rms_err_vs_oracle"] = {"pitch_out": rr(gp, refs[0]), "spectrum_out": rr(gs, refs[1].reshape(-1)), "tolerance": 1e-4}
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
     print(json.dumps(out))
     sys.stdout.flush()
+    os.dup2(2, 1)
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()

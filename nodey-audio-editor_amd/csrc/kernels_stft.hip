@@ -666,6 +666,7 @@ __global__ __launch_bounds__(kThreads, 2) void pv_synth2_kernel(SigViewD src, Pv
 #endif
                 if (r == 0 && lane == 0) y.y = 0.0f;
                 SA[lane + 64 * r] = y;
+                va[r] = y;                                   // own bin stays in registers; only the mirror bin comes from LDS
             }
             if (lane == 0) {
                 const float ph = (float)(int32_t)(qs[8] - qa[8]) * (1.0f / 4294967296.0f);
@@ -680,7 +681,7 @@ __global__ __launch_bounds__(kThreads, 2) void pv_synth2_kernel(SigViewD src, Pv
 #ifdef NAE_ABL_NO_UNSPLIT
                 const cf Xk = va[r], Xm = cf{va[r].y, va[r].x};
 #else
-                const cf Xk = SA[k], Xm = SA[512 - k];
+                const cf Xk = va[r], Xm = SA[512 - k];
 #endif
                 const cf T = tsp[r];
                 const cf E{Xk.x + Xm.x, Xk.y - Xm.y};       // 2E, 2D: the factor 1/2 lives in wsy
