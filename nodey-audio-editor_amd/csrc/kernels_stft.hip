@@ -738,7 +738,10 @@ __global__ __launch_bounds__(256) void resample_kernel(SigViewD src, RsParams p,
 // tiled rate transposer: a 256-thread workgroup produces kRsOut consecutive output frames of one stream; the
 // source span it needs (kRsOut*rho + 16 samples per channel) is staged once into LDS with 16-byte loads, the
 // 16 taps are read from LDS, and interleaved stereo output leaves as one 8-byte store per frame.
-constexpr int kRsOut = 1024;                     // output frames per workgroup
+#ifndef NAE_RS_OUT
+#define NAE_RS_OUT 512      // measured: 256 -> 3.6 ms, 512 -> 3.07, 1024 -> 3.4 (C5 mix+transposer; LDS per workgroup sets the occupancy)
+#endif
+constexpr int kRsOut = NAE_RS_OUT;                     // output frames per workgroup
 constexpr int kRsRow = 20;                       // LDS row stride of the coefficient table (16 taps + 4 pad): a 64-B
                                                  // stride maps every row to one of 4 bank slots (4-way conflicts on b128)
 constexpr int kRsMaxSpan = 4096 + 32;            // staged source samples per channel (rho <= 4)
