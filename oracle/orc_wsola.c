@@ -18,8 +18,10 @@
  * tap sums in the stereo FIR), because the data-dependent arg-max makes the order observable.
  *
  * PARITY UNPINNED: the reference ships no SoundTouch fixtures and the library cannot be built or imported here,
- * so nothing in this file has been checked against SoundTouch output.  What the tests pin is (i) the GPU path
- * against this restatement, bit for bit, and (ii) signal-level properties (length, pitch, tempo, chunk invariance).
+ * so nothing in this file has been checked against SoundTouch output.  What the tests pin is (i) this file against
+ * tests/golden/wsola_golden.npz, authored by a second, independently written restatement in numpy float32 block form
+ * (tests/golden/st_numpy.py), (ii) the GPU path against this file, bit for bit, and (iii) signal-level properties
+ * (length, pitch, tempo, chunk invariance).
  */
 #include "nae_oracle.h"
 

@@ -14,6 +14,7 @@ K8 (FFT spectrum) has no reference code; its golden is scipy.fft.rfft in float64
 (FFTW r2c convention: un-normalised forward DFT), compared under the 1e-4 relative-RMS tolerance.
 K7 (tempo/pitch) has no independent implementation to pin against (SoundTouch absent: PARITY UNPINNED); the
 file k7_regression.npz stores the ORACLE's own output for a tone so later rounds notice unintended drift.
+The SoundTouch-shaped chain (K7 option A) is authored by st_numpy.py, a separate numpy-float32 block restatement.
 """
 import os
 import sys
@@ -190,19 +191,25 @@ def main():
         k7[name + "_params"] = np.array([rate, pitch])
     np.savez_compressed(os.path.join(HERE, "k7_regression.npz"), **k7)
 
-    # ---- SoundTouch-shaped chain regression (ORACLE output of oracle/orc_wsola.c, not an independent pin: the
-    # library is absent, PARITY UNPINNED).  A two-tone stereo signal, 16 000 frames, the three stage orders.
+    # ---- SoundTouch-shaped chain (K7 option A): authored by the independent numpy block restatement st_numpy.py, so
+    # the C oracle (streaming, FIFO by FIFO) is pinned by construction as K1-K6 are; versus SoundTouch itself the chain
+    # stays PARITY UNPINNED (library absent).  A two-tone stereo signal and a mono noise signal, every stage order.
+    import st_numpy
     Lw = 16000
     n = np.arange(Lw)
     st_in = np.stack([0.5 * np.sin(2 * np.pi * 440 * n / 48000) + 0.2 * np.sin(2 * np.pi * 1234.5 * n / 48000),
                       0.4 * np.sin(2 * np.pi * 660 * n / 48000 + 1.0)], 1).astype(f32).reshape(-1)
-    ws = {"in": st_in}
-    for name, (rate, pitch) in {"pitch_up3": (1.0, 2 ** (3 / 12)), "tempo_1p25": (1.25, 0.8), "pitch_down4": (1.0, 2 ** (-4 / 12))}.items():
-        y, offs = orc.st_process(st_in, 2, 48000, rate, pitch, want_offsets=True)
+    ws = {"in": st_in, "mono_in": splitmix_uniform(12000, 77)}
+    cases = {"pitch_up3": ("in", 2, 48000, 1.0, 2 ** (3 / 12)), "tempo_1p25": ("in", 2, 48000, 1.25, 0.8),
+             "pitch_down4": ("in", 2, 48000, 1.0, 2 ** (-4 / 12)), "mono_22k_down": ("mono_in", 1, 22050, 1.0, 0.8),
+             "mono_8k_rate": ("mono_in", 1, 8000, 1.3, 1.0)}
+    for name, (src, ch, sr, rate, pitch) in cases.items():
+        y, offs = st_numpy.process(ws[src], ch, sr, rate, pitch)
         ws[name] = y
-        ws[name + "_offsets"] = offs
-        ws[name + "_params"] = np.array([rate, pitch])
-    np.savez_compressed(os.path.join(HERE, "wsola_regression.npz"), **ws)
+        ws[name + "_offsets"] = offs          # the restatement runs through all 200 flush blocks: a superset of the oracle's
+        ws[name + "_params"] = np.array([ch, sr, rate, pitch])
+        ws[name + "_src"] = np.array(src)
+    np.savez_compressed(os.path.join(HERE, "wsola_golden.npz"), **ws)
     print("wrote", [f for f in os.listdir(HERE) if f.endswith(".npz")])
 
 

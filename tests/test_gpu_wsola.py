@@ -188,11 +188,13 @@ def test_full_size_properties(ctx, nae):
     assert np.array_equal(y[0].view(np.uint32), ref.view(np.uint32))
 
 
-def test_committed_fixture(ctx, nae, golden):
-    """GPU against the committed vectors (tests/golden/wsola_regression.npz), without the oracle in the loop"""
-    g = golden["wsola_regression"]
-    for name in ("pitch_up3", "tempo_1p25", "pitch_down4"):
-        rate, pitch = g[name + "_params"]
-        y, offs, _ = gpu_wsola(ctx, nae, g["in"], 2, 48000, float(rate), float(pitch), want_offsets=True)
-        assert np.array_equal(offs[0], g[name + "_offsets"]), name
-        assert np.array_equal(y[0].view(np.uint32), g[name].view(np.uint32)), name
+@pytest.mark.parametrize("name", ["pitch_up3", "tempo_1p25", "pitch_down4", "mono_22k_down", "mono_8k_rate"])
+def test_committed_golden(ctx, nae, golden, name):
+    """GPU against the committed vectors of the independent numpy restatement (tests/golden/st_numpy.py), without the C
+    oracle in the loop"""
+    g = golden["wsola_golden"]
+    ch, sr, rate, pitch = g[name + "_params"]
+    x = g[str(g[name + "_src"])]
+    y, offs, _ = gpu_wsola(ctx, nae, x, int(ch), int(sr), float(rate), float(pitch), want_offsets=True)
+    assert np.array_equal(y[0].view(np.uint32), g[name].view(np.uint32))
+    assert np.array_equal(offs[0], g[name + "_offsets"][: offs.shape[1]])

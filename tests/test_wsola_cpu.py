@@ -109,11 +109,16 @@ def test_host_planner_rejects_what_the_reference_rejects(nae):
         nae.Context.wsola_plan(48000, 2, 0.0, 1.0, 1000)
 
 
-def test_oracle_self_regression(golden):
-    """the committed output of this oracle (tests/golden/gen_golden.py) — catches unintended drift, pins nothing else"""
-    g = golden["wsola_regression"]
-    for name in ("pitch_up3", "tempo_1p25", "pitch_down4"):
-        rate, pitch = g[name + "_params"]
-        y, offs = orc.st_process(g["in"], 2, SR, rate, pitch, want_offsets=True)
-        assert np.array_equal(offs, g[name + "_offsets"]), name
-        assert np.array_equal(y.view(np.uint32), g[name].view(np.uint32)), name
+WSOLA_CASES = ("pitch_up3", "tempo_1p25", "pitch_down4", "mono_22k_down", "mono_8k_rate")
+
+
+@pytest.mark.parametrize("name", WSOLA_CASES)
+def test_oracle_matches_the_independent_numpy_restatement(golden, name):
+    """tests/golden/wsola_golden.npz is authored by tests/golden/st_numpy.py (block form, numpy float32) — a second
+    restatement written separately from the C oracle (streaming form).  Samples and offsets must agree bit for bit."""
+    g = golden["wsola_golden"]
+    ch, sr, rate, pitch = g[name + "_params"]
+    x = g[str(g[name + "_src"])]
+    y, offs = orc.st_process(x, int(ch), int(sr), float(rate), float(pitch), want_offsets=True)
+    assert np.array_equal(y.view(np.uint32), g[name].view(np.uint32))
+    assert offs.size >= 2 and np.array_equal(offs, g[name + "_offsets"][: offs.size])
