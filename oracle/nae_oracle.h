@@ -12,7 +12,8 @@
  *      (tests/golden/gen_golden.py) — "parity pinned by construction, not by reference fixtures".
  *  (2) the builder-specified nodes K7 (tempo/pitch: phase vocoder + rate transposer) and K8 (FFT
  *      spectrum).  The reference has no code for K8 and calls SoundTouch 2.3.2 (absent) for K7, so
- *      versus the reference these are "PARITY UNPINNED"; K8 is pinned against scipy's float64 rfft.
+ *      versus the reference these are "PARITY UNPINNED"; K8 is pinned against scipy's float64 rfft and K7 against
+ *      a float64 numpy restatement of its specification (tests/golden/pv_numpy.py -> k7_golden.npz, 1e-4 tolerance).
  */
 #ifndef NAE_ORACLE_H
 #define NAE_ORACLE_H

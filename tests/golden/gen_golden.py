@@ -14,6 +14,8 @@ K8 (FFT spectrum) has no reference code; its golden is scipy.fft.rfft in float64
 (FFTW r2c convention: un-normalised forward DFT), compared under the 1e-4 relative-RMS tolerance.
 K7 (tempo/pitch) has no independent implementation to pin against (SoundTouch absent: PARITY UNPINNED); the
 file k7_regression.npz stores the ORACLE's own output for a tone so later rounds notice unintended drift.
+k7_golden.npz pins the same node to its SPECIFICATION: authored by pv_numpy.py, a float64 restatement
+with numpy's FFT, compared under the 1e-4 relative-RMS tolerance.
 The SoundTouch-shaped chain (K7 option A) is authored by st_numpy.py, a separate numpy-float32 block restatement.
 """
 import os
@@ -190,6 +192,26 @@ def main():
         k7[name] = orc.stretch(tone, 1, rate, pitch)
         k7[name + "_params"] = np.array([rate, pitch])
     np.savez_compressed(os.path.join(HERE, "k7_regression.npz"), **k7)
+
+    # ---- K7 vocoder + transposer against the SPECIFICATION: pv_numpy.py is a float64 restatement of DESIGN.md §3.3 with
+    # numpy's FFT (nothing shared with the oracle's canonical FFT / polynomial atan2).  Faded two-tone and chirp inputs:
+    # no phase-wrap decision of an energetic bin sits within float32 rounding of half a turn.
+    import pv_numpy
+    Lp = 12000
+    n = np.arange(Lp)
+    fade = np.ones(Lp)
+    fade[:2048] = 0.5 - 0.5 * np.cos(np.pi * np.arange(2048) / 2048)
+    fade[-2048:] = fade[:2048][::-1]
+    tone2 = ((0.5 * np.sin(2 * np.pi * 1000 * n / 48000) + 0.25 * np.sin(2 * np.pi * 3300 * n / 48000)) * fade).astype(f32)
+    chirp = (0.4 * np.sin(2 * np.pi * (300 * n / 48000 + 4000 * (n / 48000) ** 2)) * fade).astype(f32)
+    kg = {"mono": tone2, "stereo": np.stack([tone2, chirp], 1).reshape(-1)}
+    for name, (src, ch, rate, pitch) in {"up3": ("stereo", 2, 1.0, 2 ** (3 / 12)), "down4": ("stereo", 2, 1.0, 2 ** (-4 / 12)),
+                                         "tempo_1p5": ("stereo", 2, 1.5, 1 / 1.5), "tempo_0p7": ("stereo", 2, 0.7, 1 / 0.7),
+                                         "rate2_up5": ("mono", 1, 2.0, 2 ** (5 / 12)), "rate_0p8": ("mono", 1, 0.8, 1.0)}.items():
+        kg[name] = pv_numpy.stretch(kg[src], ch, rate, pitch).astype(f32)
+        kg[name + "_params"] = np.array([ch, rate, pitch])
+        kg[name + "_src"] = np.array(src)
+    np.savez_compressed(os.path.join(HERE, "k7_golden.npz"), **kg)
 
     # ---- SoundTouch-shaped chain (K7 option A): authored by the independent numpy block restatement st_numpy.py, so
     # the C oracle (streaming, FIFO by FIFO) is pinned by construction as K1-K6 are; versus SoundTouch itself the chain

@@ -145,6 +145,16 @@ def test_k7_identity_and_layouts(ctx, nae):
     assert np.array_equal(b.reshape(ch, pl.out_len).T.reshape(-1), a)
 
 
+@pytest.mark.parametrize("name", ["up3", "down4", "tempo_1p5", "tempo_0p7", "rate2_up5", "rate_0p8"])
+def test_k7_against_the_specification_golden(ctx, nae, golden, name):
+    """GPU against tests/golden/k7_golden.npz (float64 numpy restatement of the K7 specification), no oracle in the loop"""
+    g = golden["k7_golden"]
+    ch, rate, pitch = g[name + "_params"]
+    got, _ = gpu_stretch(ctx, nae, g[str(g[name + "_src"])], int(ch), float(rate), float(pitch))
+    assert got.size == g[name].size
+    assert rel_rms(got, g[name]) <= TOL
+
+
 def test_k7_batched_streams_are_independent(ctx, nae):
     n_streams, L, ch = 9, 12000, 2
     x = orc.fill_uniform(n_streams * L * ch, 47)

@@ -180,6 +180,20 @@ def test_k7_properties_and_regression(golden):
     assert np.array_equal(orc.stretch(x, 1, 1.0, 1.0), x)
 
 
+K7_GOLDEN = ("up3", "down4", "tempo_1p5", "tempo_0p7", "rate2_up5", "rate_0p8")
+
+
+@pytest.mark.parametrize("name", K7_GOLDEN)
+def test_k7_matches_the_specification_restatement(golden, name):
+    """tests/golden/k7_golden.npz: float64 numpy restatement of DESIGN.md §3.3 (tests/golden/pv_numpy.py) — every stage
+    order of vocoder and transposer, within BASELINE.json's float tolerance"""
+    g = golden["k7_golden"]
+    ch, rate, pitch = g[name + "_params"]
+    out = orc.stretch(g[str(g[name + "_src"])], int(ch), float(rate), float(pitch))
+    assert out.size == g[name].size
+    assert rel_rms(out, g[name]) <= 1e-4
+
+
 def test_k7_pitch_moves_a_tone():
     sr, n = 48000, 48000
     t = np.arange(n) / sr
