@@ -486,14 +486,18 @@ int st_launch_aa(nae_ctx* ctx, const StCfg& c, const StView& in, long long j0, l
 }
 
 // ------------------------------------------------------------------ CU: cubic transposer
+// One thread = one output index for kCuGroup streams: the (position, fraction) entry and the 4 weights depend on the
+// index only, so the table — as large as the output itself — is read once per group instead of once per stream
+// (the kernel is bound by memory traffic: table + 4 input frames + 1 output frame per stream-output).
+constexpr int kCuGroup = 4;
+
 template <int CH>
 __global__ __launch_bounds__(256) void st_cu_kernel(DView in, const long long* __restrict__ pos, const float* __restrict__ fr,
-                                                    long long tab_origin, long long n0, long long n1, DOut out, unsigned n_streams)
+                                                    long long tab_origin, long long n0, long long n1, DOut out, long long n_streams,
+                                                    unsigned blocks)
 {
-    // output index fastest over the grid: each stream's reads and writes stay contiguous (the alternative — streams
-    // fastest, so that neighbours share a piece of the table in L2 — measured 9 % slower)
-    const unsigned blocks = gridDim.x / n_streams;
-    const long long s = blockIdx.x / blocks;
+    // output index fastest over the grid: each stream's reads and writes stay contiguous
+    const long long s0 = (long long)(blockIdx.x / blocks) * kCuGroup;
     const long long n = n0 + (long long)(blockIdx.x % blocks) * 256 + threadIdx.x;
     if (n >= n1) return;
     const long long a = pos[n - tab_origin];
@@ -502,14 +506,26 @@ __global__ __launch_bounds__(256) void st_cu_kernel(DView in, const long long* _
     const float y1 = ((1.5f * x0 + -2.5f * x1) + 0.0f * x2) + 1.0f * x3;
     const float y2 = ((-1.5f * x0 + 2.0f * x1) + 0.5f * x2) + 0.0f * x3;
     const float y3 = ((0.5f * x0 + -0.5f * x1) + 0.0f * x2) + 0.0f * x3;
-    const float* sbase = in.v.base + s * in.v.ss;
-    float* obase = out.o.base + s * out.o.ss;
-    const Frame<CH> p0 = ld_frame<CH>(in, sbase, a), p1 = ld_frame<CH>(in, sbase, a + 1);
-    const Frame<CH> p2 = ld_frame<CH>(in, sbase, a + 2), p3 = ld_frame<CH>(in, sbase, a + 3);
-    Frame<CH> y;
+    Frame<CH> p0[kCuGroup], p1[kCuGroup], p2[kCuGroup], p3[kCuGroup];
 #pragma unroll
-    for (int c = 0; c < CH; c++) y.x[c] = ((y0 * p0.x[c] + y1 * p1.x[c]) + y2 * p2.x[c]) + y3 * p3.x[c];
-    st_frame<CH>(out, obase, n, y);
+    for (int k = 0; k < kCuGroup; k++) {
+        if (s0 + k < n_streams) {
+            const float* sbase = in.v.base + (s0 + k) * in.v.ss;
+            p0[k] = ld_frame<CH>(in, sbase, a);
+            p1[k] = ld_frame<CH>(in, sbase, a + 1);
+            p2[k] = ld_frame<CH>(in, sbase, a + 2);
+            p3[k] = ld_frame<CH>(in, sbase, a + 3);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kCuGroup; k++) {
+        if (s0 + k < n_streams) {
+            Frame<CH> y;
+#pragma unroll
+            for (int c = 0; c < CH; c++) y.x[c] = ((y0 * p0[k].x[c] + y1 * p1[k].x[c]) + y2 * p2[k].x[c]) + y3 * p3[k].x[c];
+            st_frame<CH>(out, out.o.base + (s0 + k) * out.o.ss, n, y);
+        }
+    }
 }
 
 int st_launch_cu(nae_ctx* ctx, const StCfg& c, const StView& in, const long long* d_pos, const float* d_fract,
@@ -517,22 +533,23 @@ int st_launch_cu(nae_ctx* ctx, const StCfg& c, const StView& in, const long long
 {
     if (n1 <= n0 || n_streams == 0) return NAE_OK;
     const long long blocks = (n1 - n0 + 255) / 256;
-    // one launch covers at most 2^31 - 1 workgroups: chunk the streams if a batch is larger than that
-    const size_t max_ns = (size_t)(0x7fffffffll / blocks);
-    if (max_ns == 0) return nae_fail(ctx, NAE_ERR_INVALID, "cubic transposer: range too long for one launch");
+    if (blocks > 0x7fffffffll) return nae_fail(ctx, NAE_ERR_INVALID, "cubic transposer: range too long for one launch");
+    // one launch covers at most 2^31 - 1 workgroups: chunk the stream groups if a batch is larger than that
+    const size_t max_groups = (size_t)(0x7fffffffll / blocks);
+    const size_t max_ns = max_groups * kCuGroup;
     for (size_t s0 = 0; s0 < n_streams; s0 += max_ns) {
-        const unsigned ns = (unsigned)((n_streams - s0 < max_ns) ? n_streams - s0 : max_ns);
+        const size_t ns = (n_streams - s0 < max_ns) ? n_streams - s0 : max_ns;
         StView vin = in;
         vin.base += (long long)s0 * in.ss;
         StOut vout = out;
         vout.base += (long long)s0 * out.ss;
-        const unsigned grid = (unsigned)(blocks * ns);
+        const unsigned grid = (unsigned)(blocks * ((ns + kCuGroup - 1) / kCuGroup));
         if (c.ch == 2)
             NAE_KLAUNCH(ctx, "st_cu_kernel", (st_cu_kernel<2>), dim3(grid), dim3(256), 0, ctx->stream, dview(vin, 2), d_pos, d_fract,
-                        tab_origin, n0, n1, dout(vout, 2), ns);
+                        tab_origin, n0, n1, dout(vout, 2), (long long)ns, (unsigned)blocks);
         else
             NAE_KLAUNCH(ctx, "st_cu_kernel", (st_cu_kernel<1>), dim3(grid), dim3(256), 0, ctx->stream, dview(vin, 1), d_pos, d_fract,
-                        tab_origin, n0, n1, dout(vout, 1), ns);
+                        tab_origin, n0, n1, dout(vout, 1), (long long)ns, (unsigned)blocks);
     }
     return nae_check(ctx, hipGetLastError(), "st_cu_kernel");
 }
