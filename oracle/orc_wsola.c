@@ -67,6 +67,7 @@ static float* fifo_end(fifo* f, size_t need)
 static void fifo_commit(fifo* f, size_t n) { f->cnt += n; }
 static void fifo_put(fifo* f, const float* src, size_t n)
 {
+    if (n == 0) return;
     float* e = fifo_end(f, n);
     memcpy(e, src, n * (size_t)f->ch * sizeof(float));
     f->cnt += n;
