@@ -1104,7 +1104,7 @@ int nae_launch_pv_synth(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig*
     const unsigned grid = (unsigned)((items + kWaves - 1) / kWaves);
     const size_t lds = kLdsTables + kWaves * kLdsPerWavePv;
     // few long tiles (<= one 512-thread workgroup per CU): the 2-waves-per-SIMD build has 256 VGPRs and no spills
-    const bool low_occ = grid <= 256 || ctx->dbg_pv_lowocc;
+    const bool low_occ = (grid <= 256 || ctx->dbg_pv_lowocc) && !ctx->dbg_pv_highocc;
 #define NAE_SYNTH(U, O) NAE_KLAUNCH(ctx, "pv_synth_kernel", (pv_synth_kernel<U, O>), dim3(grid), dim3(kThreads), lds, ctx->stream, \
                                     to_view(src), p, items, phase_ws, to_out(out), tb)
     if (low_occ && !ctx->dbg_pv_no_pipeline) {

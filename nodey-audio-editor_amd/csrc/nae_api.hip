@@ -185,6 +185,7 @@ int nae_ctx_create(int device, nae_ctx** out)
     ctx->own_stream = true;
     if (const char* t = getenv("NAE_PV_TILE")) ctx->pv_tile = atoi(t) > 0 ? atoi(t) : 0;   // tuning knob (0 = automatic)
     ctx->dbg_pv_lowocc = getenv("NAE_PV_LOWOCC") != nullptr;
+    ctx->dbg_pv_highocc = getenv("NAE_PV_HIGHOCC") != nullptr;
     ctx->dbg_pv_no_pipeline = getenv("NAE_PV_NO_PIPELINE") != nullptr;
     ctx->dbg_rs_single = getenv("NAE_RS_SINGLE") != nullptr;
     ctx->dbg_no_mix_fuse = getenv("NAE_NO_MIX_FUSE") != nullptr;

@@ -27,6 +27,7 @@ struct nae_ctx {
     struct nae_wsola_cache* wsola_cache = nullptr;   // plan + workspaces of nae_wsola_block_f32 (nae_wsola.hip)
     int pv_tile = 0;             // frames per phase-vocoder tile; 0 = choose per call (nae_pick_pv_tile)
     // tuning / A-B switches, read once from the environment at context creation (tools/ab.sh)
+    bool dbg_pv_highocc = false;     // NAE_PV_HIGHOCC: force the 4-waves-per-SIMD synth build (A/B only)
     bool dbg_pv_lowocc = false;      // NAE_PV_LOWOCC: force the 2-waves-per-SIMD synth build
     int dbg_pv_lockstep = 8;         // NAE_PV_LOCKSTEP=N: workgroup barrier every N frames in the pipelined synth kernel (0: never)
     int dbg_td_nc = 0;               // NAE_TD_NC=1|2|4: candidates per thread of the WSOLA search (0: by batch size)
