@@ -103,6 +103,9 @@ constexpr int kSpecChunk = 32;
 #ifndef NAE_SPEC_OCC
 #define NAE_SPEC_OCC 4
 #endif
+#ifndef NAE_SPEC_LAUNDER
+#define NAE_SPEC_LAUNDER 1
+#endif
 __global__ __launch_bounds__(kThreads, NAE_SPEC_OCC) void spectrum_stereo_kernel(const float* __restrict__ src, long long src_ss, long long T,
                                                                      long long n_frames, long long chunks_per_stream,
                                                                      long long n_items, float* __restrict__ dst,
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(kThreads, NAE_SPEC_OCC) void spectrum_stereo_kernel
 #pragma unroll
                 for (int j = 0; j < 8; j++) v0[j] = v1[j];
             }
-            fft512_fwd(v0, L.scratch, tw, lane);
+            fft512_fwd<NAE_SPEC_LAUNDER>(v0, L.scratch, tw, lane);
             const cf nyq = rfft_split(v0, L.scratch, L.t1024, lane);
 #pragma unroll
             for (int r = 0; r < 8; r++) o[lane + 64 * r] = NAE_SPEC_SQRT(v0[r].x * v0[r].x + v0[r].y * v0[r].y);
@@ -389,7 +392,7 @@ __global__ __launch_bounds__(kThreads, kOcc) void pv_synth_kernel(SigViewD src, 
             load_frame_windowed<kUnit>(v, in, s, L.hann, lane);
 #pragma unroll 1
         for (int half = 0; half < 2; half++) {
-            fft512_fwd<(kOcc > 2)>(v, L.scratch, tw, lane);
+            fft512_fwd<(kOcc > 2 ? 2 : 0)>(v, L.scratch, tw, lane);
             if (half == 0) {
                 const cf nyq = kRegTab ? rfft_split_reg(v, L.scratch, tsp, tsp_nyq, lane) : rfft_split(v, L.scratch, L.t1024, lane);
                 uint32_t qa[9];
@@ -602,7 +605,7 @@ __global__ __launch_bounds__(kThreads, 2) void pv_synth2_kernel(SigViewD src, Pv
         if (f + 1 < f_end) load_frame_raw<kUnit>(nxt, in, frame_start(p, f + 1), lane);
 #ifndef NAE_ABL_NO_FFT
         if (have) fft512_fwd2(va, zs, SA, SS, tw, lane);
-        else fft512_fwd<false>(va, SA, tw, lane);
+        else fft512_fwd<0>(va, SA, tw, lane);
 #endif
         // ---- phase P1: split exchange (write Z) | overlap-add of frame fz
 #pragma unroll
@@ -694,7 +697,7 @@ __global__ __launch_bounds__(kThreads, 2) void pv_synth2_kernel(SigViewD src, Pv
         }
     }
     if (have) {   // drain the last synthesised frame
-        fft512_fwd<false>(zs, SS, tw, lane);
+        fft512_fwd<0>(zs, SS, tw, lane);
         ola_emit(zs, fz);
     }
 }

@@ -82,13 +82,16 @@ __device__ __forceinline__ int kl_of_lane(int lane) { return lane; }
 //   T2  element u2[q][p][m]  at  (q ^ ((m & 3) << 1)) | ((p ^ (m >> 2)) << 3) | (m << 6)
 // (address bits are an invertible GF(2) map of the index bits whose low 4 / 5 bits are a bijection of the
 //  lane bits that vary inside one write / read group).
-template <bool kLaunder = true>
+// kLaunder: the 32 swizzled LDS addresses below are loop-invariant, and hoisting them out of the frame loop pins 32
+// VGPRs.  2 = recompute all of them per call (~75 instructions; the 128-VGPR vocoder builds), 1 = recompute only the 14
+// that are one XOR each and keep the 16 two-to-three-instruction ones hoisted (the spectrum kernel: +16 VGPRs, -36
+// instructions per FFT), 0 = keep everything hoisted (the 256-VGPR build).
+template <int kLaunder = 2>
 __device__ __forceinline__ void fft512_fwd(cf (&v)[8], cf* __restrict__ scratch, const FftTw& tw, int lane)
 {
-    // kLaunder: the 32 swizzled LDS addresses below are loop-invariant, and hoisting them out of the frame loop
-    // pins 32 VGPRs; at 128 VGPRs that spills, so the lane id is laundered and they are recomputed (~75
-    // instructions per FFT).  The 256-VGPR build keeps them hoisted.
-    if (kLaunder) asm volatile("" : "+v"(lane));
+    int lane_x = lane;                                   // feeds the XOR-with-constant addresses
+    if (kLaunder >= 1) asm volatile("" : "+v"(lane_x));
+    if (kLaunder >= 2) asm volatile("" : "+v"(lane));
     const int m = lane & 7, qq = lane >> 3;
     // pass A
     dft8_fwd(v);
@@ -96,7 +99,7 @@ __device__ __forceinline__ void fft512_fwd(cf (&v)[8], cf* __restrict__ scratch,
     for (int q = 1; q < 8; q++) v[q] = cmul_tw(v[q], tw.a[q - 1]);
     // transpose 1: u1[q][l] -> lane (m, qq) register j = u1[qq][m + 8 j]
 #pragma unroll
-    for (int q = 0; q < 8; q++) scratch[(lane ^ (q << 3)) + 64 * q] = v[q];
+    for (int q = 0; q < 8; q++) scratch[(lane_x ^ (q << 3)) + 64 * q] = v[q];
     wave_lds_sync();
     {
         const int base = m + 64 * qq;
@@ -117,7 +120,7 @@ __device__ __forceinline__ void fft512_fwd(cf (&v)[8], cf* __restrict__ scratch,
     }
     wave_lds_sync();
 #pragma unroll
-    for (int j = 0; j < 8; j++) v[j] = scratch[(lane ^ (((j & 3) << 1) | ((j >> 2) << 3))) + 64 * j];
+    for (int j = 0; j < 8; j++) v[j] = scratch[(lane_x ^ (((j & 3) << 1) | ((j >> 2) << 3))) + 64 * j];
     wave_lds_sync();
     // pass C
     dft8_fwd(v);
