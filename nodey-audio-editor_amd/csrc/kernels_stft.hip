@@ -203,7 +203,7 @@ __device__ __forceinline__ void phases_of(const cf (&v)[8], cf nyq, uint32_t (&q
 #else
 #pragma unroll
     for (int r = 0; r < 8; r++) qa[r] = atan2_q32(v[r].y, v[r].x);
-    qa[8] = atan2_q32(nyq.y, nyq.x);
+    qa[8] = (nyq.x < 0.0f) ? 0x80000000u : 0u;     // bin N/2 of a real signal is real
 #endif
 }
 

@@ -307,7 +307,10 @@ static void pv_channel(const float* src, size_t L, int ch, int c, const orc_stre
             xw[n] = x * HANN[n];
         }
         rfft1024(xw, X);
-        for (int k = 0; k < NAE_FFT_BINS; k++) qa[k] = (uint32_t)orc_atan2_q32(X[k].y, X[k].x);
+        for (int k = 0; k < NAE_FFT_BINS - 1; k++) qa[k] = (uint32_t)orc_atan2_q32(X[k].y, X[k].x);
+        /* bin N/2 of a real signal is real: its phase is 0 or half a turn, read off the sign of the real part (the
+         * imaginary part the split leaves behind is rounding residue of the order of 1e-16 relative) */
+        qa[NAE_FFT_BINS - 1] = (X[NAE_FFT_BINS - 1].x < 0.0f) ? 0x80000000u : 0u;
         if (f == 0)
             memcpy(qs, qa, sizeof qs);
         else {
