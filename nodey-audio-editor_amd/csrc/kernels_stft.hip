@@ -537,14 +537,15 @@ __global__ __launch_bounds__(kThreads, 2) void pv_synth2_kernel(SigViewD src, Pv
         qp[8] = 0;
     }
     // wsy = synthesis window with every constant of the tolerance path folded in: 1/512 (inverse FFT), 1/2 (the
-    // halves dropped from the c2r pre-twiddle below) and 2/3 (overlap-add gain); the sign of the odd sample undoes
+    // halves dropped from the c2r pre-twiddle below), 1/2 (the halves dropped from the analysis split) and 2/3
+    // (overlap-add gain); the sign of the odd sample undoes
     // the conjugation of the inverse-by-forward FFT
     cf win[8], wsy[8], tsp[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         const float2 w = *reinterpret_cast<const float2*>(hann + 2 * (lane + 64 * j));
         win[j] = cf{w.x, w.y};
-        wsy[j] = cf{w.x * (NAE_OLA_GAIN / 1024.0f), -w.y * (NAE_OLA_GAIN / 1024.0f)};
+        wsy[j] = cf{w.x * (NAE_OLA_GAIN / 2048.0f), -w.y * (NAE_OLA_GAIN / 2048.0f)};
         tsp[j] = t1024[lane + 64 * j];
     }
     const cf tsp_nyq = t1024[512];
@@ -613,10 +614,12 @@ __global__ __launch_bounds__(kThreads, 2) void pv_synth2_kernel(SigViewD src, Pv
         wave_lds_sync();
         // ---- phase P2: split (mirror read) -> X | store the completed block of frame fz
         cf nyq;
+        // (the split below yields 2 X: its halves are folded into wsy — phases are scale-invariant, the magnitude is
+        //  restored by the synthesis window, and a factor 2 is exact in every product on the way)
         {
             const cf A = SA[0];
-            const cf E = cf{0.5f * (A.x + A.x), 0.5f * (A.y - A.y)};
-            const cf O = cf{0.5f * (A.x - A.x), 0.5f * (A.y + A.y)};
+            const cf E = cf{A.x + A.x, A.y - A.y};
+            const cf O = cf{A.x - A.x, A.y + A.y};
             const cf P = cmul_tw(O, tsp_nyq);
             nyq = cf{E.x + P.y, E.y - P.x};
         }
@@ -629,8 +632,8 @@ __global__ __launch_bounds__(kThreads, 2) void pv_synth2_kernel(SigViewD src, Pv
 #else
             const cf B = SA[(512 - k) & 511];
 #endif
-            const cf E = cf{0.5f * (A.x + B.x), 0.5f * (A.y - B.y)};
-            const cf O = cf{0.5f * (A.x - B.x), 0.5f * (A.y + B.y)};
+            const cf E = cf{A.x + B.x, A.y - B.y};
+            const cf O = cf{A.x - B.x, A.y + B.y};
             const cf P = cmul_tw(O, tsp[r]);
             va[r] = cf{E.x + P.y, E.y - P.x};
         }

@@ -243,9 +243,8 @@ __device__ __forceinline__ uint32_t atan2_q32(float im, float re)
     if (sw) p = 0.25f - p;
     if (re < 0.0f) p = 0.5f - p;
     if (im < 0.0f) p = -p;
-    float f = p * 4294967296.0f;
-    if (f >= 2147483648.0f) f -= 4294967296.0f;
-    const int32_t r = (int32_t)__builtin_rintf(f);
+    // turns -> Q0.32, round to nearest, saturating (v_cvt_i32_f32 saturates: +0.5 turn -> 0x7fffffff, as in the oracle)
+    const int32_t r = __float2int_rn(p * 4294967296.0f);
     return (mx > 0.0f) ? (uint32_t)r : 0u;
 }
 

@@ -178,9 +178,10 @@ int32_t orc_atan2_q32(float im, float re)
     if (ay > ax) p = 0.25f - p;
     if (re < 0.0f) p = 0.5f - p;
     if (im < 0.0f) p = -p;
-    float f = p * 4294967296.0f;
-    if (f >= 2147483648.0f) f -= 4294967296.0f;
-    return (int32_t)rintf(f);
+    /* turns -> Q0.32, round to nearest, SATURATING: exactly half a turn (p = +0.5) becomes 0x7fffffff, one unit below
+     * the wrapping value; the conversion is then a single saturating float->int instruction on the GPU */
+    const float f = rintf(p * 4294967296.0f);
+    return (f >= 2147483648.0f) ? INT32_MAX : (int32_t)f;
 }
 
 /* ------------------------------------------------------------------------------------------ K8 */

@@ -165,7 +165,9 @@ def test_atan2_q32():
     assert L.orc_atan2_q32(0.0, 0.0) == 0
     assert L.orc_atan2_q32(0.0, 1.0) == 0
     assert L.orc_atan2_q32(1.0, 0.0) == 2 ** 30           # quarter turn
-    assert L.orc_atan2_q32(0.0, -1.0) == -2 ** 31         # half turn wraps
+    assert L.orc_atan2_q32(0.0, -1.0) == 2 ** 31 - 1      # exactly half a turn saturates
+    assert L.orc_atan2_q32(-0.0, -1.0) in (2 ** 31 - 1, -2 ** 31)
+    assert L.orc_atan2_q32(-1e-30, -1.0) == -2 ** 31
 
 
 def test_k7_properties_and_regression(golden):
