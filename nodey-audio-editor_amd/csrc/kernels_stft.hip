@@ -95,7 +95,7 @@ constexpr int kSpecChunk = 32;
 #ifdef NAE_ABL_FAST_SQRT
 #define NAE_SPEC_SQRT(x) __builtin_amdgcn_sqrtf(x)
 #else
-#define NAE_SPEC_SQRT(x) __builtin_sqrtf(x)     // correctly rounded: spectrum output is bit-identical to the oracle
+#define NAE_SPEC_SQRT(x) sqrt_rn(x)              // correctly rounded: spectrum output is bit-identical to the oracle
 #endif
 // Consecutive frames overlap by 768 of 1024 sample-frames = 6 of the 8 register rows of the FFT input layout
 // (pair index n = lane + 64 j, hop = 128 pairs = 2 rows), so the raw samples are kept in registers and each new
@@ -150,10 +150,12 @@ __global__ __launch_bounds__(kThreads, NAE_SPEC_OCC) void spectrum_stereo_kernel
                 for (int j = 0; j < 8; j++) v0[j] = v1[j];
             }
             fft512_fwd<NAE_SPEC_LAUNDER>(v0, L.scratch, tw, lane);
-            const cf nyq = rfft_split(v0, L.scratch, L.t1024, lane);
+            // 2 X from the split; |2 X|^2 = 4 |X|^2 and sqrt(4 a) = 2 sqrt(a) are exact scalings, so 0.5 * sqrt(.) is
+            // the canonical magnitude bit for bit (for |X| above ~1e-18, where no square is denormal)
+            const cf nyq = rfft_split<true>(v0, L.scratch, L.t1024, lane);
 #pragma unroll
-            for (int r = 0; r < 8; r++) o[lane + 64 * r] = NAE_SPEC_SQRT(v0[r].x * v0[r].x + v0[r].y * v0[r].y);
-            if (lane == 0) o[512] = NAE_SPEC_SQRT(nyq.x * nyq.x + nyq.y * nyq.y);
+            for (int r = 0; r < 8; r++) o[lane + 64 * r] = 0.5f * NAE_SPEC_SQRT(v0[r].x * v0[r].x + v0[r].y * v0[r].y);
+            if (lane == 0) o[512] = 0.5f * NAE_SPEC_SQRT(nyq.x * nyq.x + nyq.y * nyq.y);
             o += NAE_FFT_BINS;
         }
     }
@@ -190,7 +192,7 @@ __device__ __forceinline__ cf analyse(cf (&v)[8], const ChanView& in, long long 
 {
     load_frame_windowed<kUnit>(v, in, s, L.hann, lane);
     fft512_fwd(v, L.scratch, tw, lane);
-    return rfft_split(v, L.scratch, L.t1024, lane);
+    return rfft_split<true>(v, L.scratch, L.t1024, lane);   // 2 X: only phases are taken from it (pass 1)
 }
 
 // NAE_ABL_* macros: timing-only ablation builds for tools/ab.sh (wrong results by construction; never shipped)

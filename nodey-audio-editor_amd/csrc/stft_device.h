@@ -165,9 +165,13 @@ __device__ __forceinline__ void fft512_fwd2(cf (&a)[8], cf (&b)[8], cf* __restri
 
 // canonical r2c split.  in: v[r] = Z[kl + 64 r].  out: v[r] = X[kl + 64 r]; returns X[512] (meaningful on lane 0).
 // Leaves Z in natural order in scratch[0..511].
+// kTwice: deliver 2 X instead of X (the two 1/2 factors are skipped; a factor 2 is exact in every operation below, so
+// 2 X is bit-for-bit twice the canonical X).  For callers that only need phases, or that halve the result later.
+template <bool kTwice = false>
 __device__ __forceinline__ cf rfft_split(cf (&v)[8], cf* __restrict__ scratch, const cf* __restrict__ t1024,
                                          int lane)
 {
+    constexpr float h = kTwice ? 1.0f : 0.5f;
     const int kl = kl_of_lane(lane);
 #pragma unroll
     for (int r = 0; r < 8; r++) scratch[kl + 64 * r] = v[r];
@@ -176,8 +180,8 @@ __device__ __forceinline__ cf rfft_split(cf (&v)[8], cf* __restrict__ scratch, c
     {
         // k = 512: A = B = Z[0]
         const cf A = scratch[0];
-        const cf E = cf{0.5f * (A.x + A.x), 0.5f * (A.y - A.y)};
-        const cf O = cf{0.5f * (A.x - A.x), 0.5f * (A.y + A.y)};
+        const cf E = kTwice ? cf{A.x + A.x, A.y - A.y} : cf{h * (A.x + A.x), h * (A.y - A.y)};
+        const cf O = kTwice ? cf{A.x - A.x, A.y + A.y} : cf{h * (A.x - A.x), h * (A.y + A.y)};
         const cf P = cmul_tw(O, t1024[512]);
         nyq = cf{E.x + P.y, E.y - P.x};
     }
@@ -186,8 +190,8 @@ __device__ __forceinline__ cf rfft_split(cf (&v)[8], cf* __restrict__ scratch, c
         const int k = kl + 64 * r;
         const cf A = v[r];
         const cf B = scratch[(512 - k) & 511];
-        const cf E = cf{0.5f * (A.x + B.x), 0.5f * (A.y - B.y)};
-        const cf O = cf{0.5f * (A.x - B.x), 0.5f * (A.y + B.y)};
+        const cf E = kTwice ? cf{A.x + B.x, A.y - B.y} : cf{h * (A.x + B.x), h * (A.y - B.y)};
+        const cf O = kTwice ? cf{A.x - B.x, A.y + B.y} : cf{h * (A.x - B.x), h * (A.y + B.y)};
         const cf P = cmul_tw(O, t1024[k]);
         v[r] = cf{E.x + P.y, E.y - P.x};
     }
@@ -221,6 +225,18 @@ __device__ __forceinline__ cf rfft_split_reg(cf (&v)[8], cf* __restrict__ scratc
     }
     wave_lds_sync();
     return nyq;
+}
+
+// correctly rounded square root for x = 0, inf, NaN and every x >= 2^-96: v_sqrt_f32 (<= 1 ulp) plus the two-sided
+// residual test of the compiler's own expansion, without its rescaling of tiny arguments (5 of its 15 instructions).
+__device__ __forceinline__ float sqrt_rn(float x)
+{
+    float s = __builtin_amdgcn_sqrtf(x);
+    const float s_dn = __uint_as_float(__float_as_uint(s) - 1u), s_up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float r_dn = __builtin_fmaf(-s_dn, s, x), r_up = __builtin_fmaf(-s_up, s, x);
+    s = (r_dn <= 0.0f) ? s_dn : s;
+    s = (r_up > 0.0f) ? s_up : s;
+    return s;
 }
 
 // canonical atan2 in turns -> Q0.32
