@@ -941,51 +941,79 @@ __global__ __launch_bounds__(256) void mix_resample_tile_kernel(MixFuseD f, RsPa
     const long long own_lo = blockIdx.x == 0 ? 0 : idx_first;
     const long long own_hi = last ? p.src_len : idx_of(j1);
     const bool mix_planar = f.mix_fs == 1;
-    // two frames per thread and trip.  For every trip the loads of all NS streams are issued before anything is
-    // stored: the staging is latency-bound (one round trip to HBM per trip), so this cuts the trips by NS.
+    // four frames per thread and trip (a 512-output tile spans ~640 source frames: one trip).  The loads of all NS
+    // streams are issued before anything is stored — the staging is bound by round trips to HBM — and the mix leaves
+    // as 16-byte stores per plane, like the stand-alone mix kernel's.
     const long long m_end = last ? (p.src_len > m_hi ? p.src_len : m_hi) : m_hi;
-    for (long long m = m_lo + 2 * threadIdx.x; m < m_end; m += 2 * 256) {
-        float4 xa[NS], xb[NS];
-        const bool inside = m >= 0 && m + 2 <= p.src_len;
+    for (long long m = m_lo + 4 * threadIdx.x; m < m_end; m += 4 * 256) {
+        float4 xa[NS][2], xb[NS][2];
+        const bool inside = m >= 0 && m + 4 <= p.src_len;
 #pragma unroll
         for (int k = 0; k < NS; k++) {
-            xa[k] = xb[k] = float4{0.0f, 0.0f, 0.0f, 0.0f};
+            xa[k][0] = xa[k][1] = xb[k][0] = xb[k][1] = float4{0.0f, 0.0f, 0.0f, 0.0f};
             if (s0 + k < n_streams) {
                 const float* __restrict__ a = f.a + (s0 + k) * f.a_ss;
                 const float* __restrict__ b = f.b + (s0 + k) * f.b_ss;
                 if (inside) {
-                    xa[k] = *reinterpret_cast<const float4*>(a + 2 * m);
-                    xb[k] = *reinterpret_cast<const float4*>(b + 2 * m);
+                    xa[k][0] = *reinterpret_cast<const float4*>(a + 2 * m);
+                    xa[k][1] = *reinterpret_cast<const float4*>(a + 2 * m + 4);
+                    xb[k][0] = *reinterpret_cast<const float4*>(b + 2 * m);
+                    xb[k][1] = *reinterpret_cast<const float4*>(b + 2 * m + 4);
                 } else {
-                    if (m >= 0 && m < p.src_len) { xa[k].x = a[2 * m]; xa[k].y = a[2 * m + 1]; xb[k].x = b[2 * m]; xb[k].y = b[2 * m + 1]; }
-                    if (m + 1 >= 0 && m + 1 < p.src_len) { xa[k].z = a[2 * m + 2]; xa[k].w = a[2 * m + 3]; xb[k].z = b[2 * m + 2]; xb[k].w = b[2 * m + 3]; }
+                    float ta[8], tb[8];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const bool ok = m + e >= 0 && m + e < p.src_len;
+                        ta[2 * e] = ok ? a[2 * (m + e)] : 0.0f;
+                        ta[2 * e + 1] = ok ? a[2 * (m + e) + 1] : 0.0f;
+                        tb[2 * e] = ok ? b[2 * (m + e)] : 0.0f;
+                        tb[2 * e + 1] = ok ? b[2 * (m + e) + 1] : 0.0f;
+                    }
+                    xa[k][0] = float4{ta[0], ta[1], ta[2], ta[3]}; xa[k][1] = float4{ta[4], ta[5], ta[6], ta[7]};
+                    xb[k][0] = float4{tb[0], tb[1], tb[2], tb[3]}; xb[k][1] = float4{tb[4], tb[5], tb[6], tb[7]};
                 }
             }
         }
-        const bool own0 = m >= own_lo && m < own_hi, own1 = m + 1 >= own_lo && m + 1 < own_hi;
-        const bool in0 = m >= 0 && m < p.src_len, in1 = m + 1 >= 0 && m + 1 < p.src_len;
+        bool own[4], in[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            own[e] = m + e >= own_lo && m + e < own_hi;
+            in[e] = m + e >= 0 && m + e < p.src_len;
+        }
+        const bool own_all = own[0] && own[3];
 #pragma unroll
         for (int k = 0; k < NS; k++) {
             if (s0 + k < n_streams) {
-                float4 y;
-                y.x = in0 ? (0.0f + xa[k].x * f.va) + xb[k].x * f.vb : 0.0f;
-                y.y = in0 ? (0.0f + xa[k].y * f.va) + xb[k].y * f.vb : 0.0f;
-                y.z = in1 ? (0.0f + xa[k].z * f.va) + xb[k].z * f.vb : 0.0f;
-                y.w = in1 ? (0.0f + xa[k].w * f.va) + xb[k].w * f.vb : 0.0f;
-                if (m < m_hi) *reinterpret_cast<float4*>(stage + (size_t)k * 2 * span_alloc + 2 * (m - m_lo)) = y;   // (m_hi - m_lo) + 1 <= span_alloc
-                float* __restrict__ mx = f.mix + (s0 + k) * f.mix_ss;
-                if (own0 && own1 && mix_planar) {
-                    *reinterpret_cast<float2*>(mx + m) = float2{y.x, y.z};
-                    *reinterpret_cast<float2*>(mx + f.mix_cs + m) = float2{y.y, y.w};
+                float y[8];
+                const float av[8] = {xa[k][0].x, xa[k][0].y, xa[k][0].z, xa[k][0].w, xa[k][1].x, xa[k][1].y, xa[k][1].z, xa[k][1].w};
+                const float bv[8] = {xb[k][0].x, xb[k][0].y, xb[k][0].z, xb[k][0].w, xb[k][1].x, xb[k][1].y, xb[k][1].z, xb[k][1].w};
+#pragma unroll
+                for (int i = 0; i < 8; i++) y[i] = in[i >> 1] ? (0.0f + av[i] * f.va) + bv[i] * f.vb : 0.0f;
+                float* stg = stage + (size_t)k * 2 * span_alloc + 2 * (m - m_lo);
+                if (m + 3 < m_hi) {
+                    *reinterpret_cast<float4*>(stg) = float4{y[0], y[1], y[2], y[3]};
+                    *reinterpret_cast<float4*>(stg + 4) = float4{y[4], y[5], y[6], y[7]};
                 } else {
-                    if (own0) { mx[m * f.mix_fs] = y.x; mx[f.mix_cs + m * f.mix_fs] = y.y; }
-                    if (own1) { mx[(m + 1) * f.mix_fs] = y.z; mx[f.mix_cs + (m + 1) * f.mix_fs] = y.w; }
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        if (m + e < m_hi) *reinterpret_cast<float2*>(stg + 2 * e) = float2{y[2 * e], y[2 * e + 1]};
+                }
+                float* __restrict__ mx = f.mix + (s0 + k) * f.mix_ss;
+                if (own_all && mix_planar) {
+                    *reinterpret_cast<float4*>(mx + m) = float4{y[0], y[2], y[4], y[6]};
+                    *reinterpret_cast<float4*>(mx + f.mix_cs + m) = float4{y[1], y[3], y[5], y[7]};
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        if (own[e]) { mx[(m + e) * f.mix_fs] = y[2 * e]; mx[f.mix_cs + (m + e) * f.mix_fs] = y[2 * e + 1]; }
                 }
             }
         }
     }
     __syncthreads();
+#ifndef NAE_ABL_NO_TAPS
     rs_apply_stereo<NS>(stab, stage, span_alloc, p, j0, j1, m_lo, out, s0, n_streams);
+#endif
 }
 
 } // namespace nae
@@ -1185,8 +1213,10 @@ int nae_launch_mix_resample(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_
     auto inter16 = [](const nae_sig* v) {
         return v->chan_stride == 1 && v->frame_stride == 2 && (reinterpret_cast<uintptr_t>(v->base) & 15) == 0 && (v->stream_stride & 3) == 0;
     };
-    const bool mix_ok = (reinterpret_cast<uintptr_t>(mix_out->base) & 7) == 0 && (mix_out->stream_stride & 1) == 0 &&
-                        ((mix_out->frame_stride == 1 && (mix_out->chan_stride & 1) == 0) || mix_out->frame_stride >= 2);
+    // planar mix output: 16-byte stores per plane; interleaved (or any other) layout: scalar stores
+    const bool mix_ok = mix_out->frame_stride != 1 ||
+                        ((reinterpret_cast<uintptr_t>(mix_out->base) & 15) == 0 && (mix_out->stream_stride & 3) == 0 &&
+                         (mix_out->chan_stride & 3) == 0);
     if (ctx->dbg_no_mix_fuse || !inter16(a) || !inter16(b) || !mix_ok || span_need > kRsMaxSpan || span_alloc > 1536 || n_streams == 0 ||
         pl->mid_len == 0 || S == 0)
         return 1;
