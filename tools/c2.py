@@ -18,6 +18,9 @@ inter = lambda t: nae.Sig.interleaved(t.ptr, S2, 2)
 planar = lambda t: nae.Sig.planar(t.ptr, S2, 2)
 ms = timed(lambda: ctx.gain_sig(inter(d_x), inter(d_y), S2, 2, n3, vol))
 print("fused gain: %.3f ms  %.0f GB/s (16 B per sample-frame)" % (ms, n3 * S2 * 16 / ms / 1e6))
+import numpy as np
+ms = timed(lambda: ctx.gain(np.float32, [d_x.ptr], [d_y.ptr], n3 * S2 * 2, vol))
+print("K1 gain, one 819 MB plane: %.3f ms  %.0f GB/s" % (ms, n3 * S2 * 16 / ms / 1e6))
 ms = timed(lambda: ctx.copy_sig(inter(d_x), planar(d_p), S2, 2, n3))
 print("split (i2p): %.3f ms  %.0f GB/s" % (ms, n3 * S2 * 16 / ms / 1e6))
 ms = timed(lambda: ctx.copy_sig(planar(d_p), inter(d_y), S2, 2, n3))

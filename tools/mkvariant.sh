@@ -10,7 +10,7 @@ STFT="-fno-slp-vectorize"
 for a in "$@"; do
   if [ "$a" == "+slp" ]; then STFT=""; else STFT="$STFT $a"; fi
 done
-for f in nae_api nae_stream kernels_nodes nae_wsola; do /opt/rocm/bin/hipcc $COMMON -c $D/csrc/$f.hip -o /tmp/v_$f.o 2>/dev/null & done
+for f in nae_api nae_stream kernels_nodes nae_wsola; do /opt/rocm/bin/hipcc $COMMON $NODEFLAGS -c $D/csrc/$f.hip -o /tmp/v_$f.o 2>/dev/null & done
 /opt/rocm/bin/hipcc $COMMON $STFT -c $D/csrc/kernels_stft.hip -o /tmp/v_kernels_stft.o 2>/dev/null &
 /opt/rocm/bin/hipcc $COMMON -fno-slp-vectorize -c $D/csrc/kernels_wsola.hip -o /tmp/v_kernels_wsola.o 2>/dev/null &
 wait
