@@ -396,15 +396,25 @@ struct AaParams {
     float h[kAaLen];
     long long j0, j1;
 };
+// the cubic transposer fused behind the filter (block mode, the two stages adjacent): a workgroup filters 1024 outputs,
+// keeps them in LDS and emits every cubic output whose 4 taps lie inside them; tiles therefore advance by 1021 and the
+// host tells each tile its first cubic output (tile_n, tiles + 1 entries).  The filtered signal never touches HBM.
+struct CuFuse {
+    const long long* pos;
+    const float* fr;
+    const int* tile_n;
+    long long n_limit;       // cubic outputs at or beyond this index are not wanted
+};
+constexpr int kAaTileFused = kAaTile - 3;
 
-template <int CH>
-__global__ __launch_bounds__(256) void st_aa_kernel(DView in, AaParams p, DOut out)
+template <int CH, bool kCubic>
+__global__ __launch_bounds__(256) void st_aa_kernel(DView in, AaParams p, DOut out, CuFuse cu)
 {
     __shared__ float tile[4 * kAaRow * CH];
     __shared__ __attribute__((aligned(16))) float hs[kAaLen];
     const int tid = threadIdx.x;
     const long long s = blockIdx.y;
-    const long long jt = p.j0 + (long long)blockIdx.x * kAaTile;
+    const long long jt = p.j0 + (long long)blockIdx.x * (kCubic ? kAaTileFused : kAaTile);
     const float* sbase = in.v.base + s * in.v.ss;
     float* obase = out.o.base + s * out.o.ss;
     for (int u = tid; u < kAaTile + kAaLen; u += 256) {
@@ -415,7 +425,7 @@ __global__ __launch_bounds__(256) void st_aa_kernel(DView in, AaParams p, DOut o
     if (tid < kAaLen) hs[tid] = p.h[tid];
     __syncthreads();
     const long long j = jt + 4 * tid;
-    if (j >= p.j1) return;
+    if (!kCubic && j >= p.j1) return;
     // 8 taps per trip: frames m = kb .. kb+10 feed outputs i = 0..3 with tap k = m - i.  Every accumulator still sees
     // its taps in increasing order (the order is observable: results are compared bit for bit).
     float ev[4][CH], od[4][CH];
@@ -456,18 +466,45 @@ __global__ __launch_bounds__(256) void st_aa_kernel(DView in, AaParams p, DOut o
                 }
             }
     }
+    Frame<CH> y[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        if (j + i < p.j1) {
-            Frame<CH> y;
-            if (CH == 2) {
+        if (CH == 2) {
 #pragma unroll
-                for (int c = 0; c < CH; c++) y.x[c] = od[i][c] + ev[i][c];
-            } else {
-                y.x[0] = (float)acc[i];
-            }
-            st_frame<CH>(out, obase, j + i, y);
+            for (int c = 0; c < CH; c++) y[i].x[c] = od[i][c] + ev[i][c];
+        } else {
+            y[i].x[0] = (float)acc[i];
         }
+    }
+    if (!kCubic) {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (j + i < p.j1) st_frame<CH>(out, obase, j + i, y[i]);
+        return;
+    }
+    // ---- fused cubic stage: the 1024 filtered frames go to LDS in natural order (the input tile is dead by now)
+    __syncthreads();
+    float* filt = tile;                                   // [1024][CH]
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int c = 0; c < CH; c++) filt[(4 * tid + i) * CH + c] = y[i].x[c];
+    __syncthreads();
+    const long long n_lo = cu.tile_n[blockIdx.x];
+    long long n_hi = cu.tile_n[blockIdx.x + 1];
+    if (n_hi > cu.n_limit) n_hi = cu.n_limit;
+    for (long long n = n_lo + tid; n < n_hi; n += 256) {
+        const int a = (int)(cu.pos[n] - jt);              // 0 <= a and a + 3 < 1024 by construction of tile_n
+        const float x2 = cu.fr[n], x1 = x2 * x2, x0 = x1 * x2, x3 = 1.0f;
+        const float y0 = ((-0.5f * x0 + 1.0f * x1) + -0.5f * x2) + 0.0f * x3;
+        const float y1 = ((1.5f * x0 + -2.5f * x1) + 0.0f * x2) + 1.0f * x3;
+        const float y2 = ((-1.5f * x0 + 2.0f * x1) + 0.5f * x2) + 0.0f * x3;
+        const float y3 = ((0.5f * x0 + -0.5f * x1) + 0.0f * x2) + 0.0f * x3;
+        Frame<CH> o;
+#pragma unroll
+        for (int c = 0; c < CH; c++)
+            o.x[c] = ((y0 * filt[a * CH + c] + y1 * filt[(a + 1) * CH + c]) + y2 * filt[(a + 2) * CH + c]) + y3 * filt[(a + 3) * CH + c];
+        st_frame<CH>(out, obase, n, o);
     }
 }
 
@@ -486,13 +523,54 @@ int st_launch_aa(nae_ctx* ctx, const StCfg& c, const StView& in, long long j0, l
         StOut vout = out;
         vout.base += (long long)s0 * out.ss;
         if (c.ch == 2)
-            NAE_KLAUNCH(ctx, "st_aa_kernel", (st_aa_kernel<2>), dim3(tiles, ns), dim3(256), 0, ctx->stream, dview(vin, 2), p,
-                        dout(vout, 2));
+            NAE_KLAUNCH(ctx, "st_aa_kernel", (st_aa_kernel<2, false>), dim3(tiles, ns), dim3(256), 0, ctx->stream, dview(vin, 2), p,
+                        dout(vout, 2), CuFuse{});
         else
-            NAE_KLAUNCH(ctx, "st_aa_kernel", (st_aa_kernel<1>), dim3(tiles, ns), dim3(256), 0, ctx->stream, dview(vin, 1), p,
-                        dout(vout, 1));
+            NAE_KLAUNCH(ctx, "st_aa_kernel", (st_aa_kernel<1, false>), dim3(tiles, ns), dim3(256), 0, ctx->stream, dview(vin, 1), p,
+                        dout(vout, 1), CuFuse{});
     }
     return nae_check(ctx, hipGetLastError(), "st_aa_kernel");
+}
+
+// filter + cubic in one launch: cubic outputs [0, n_limit) of every stream from filter input `in`; d_tile_n has tiles + 1
+// entries (st_tile_starts)
+int st_launch_aa_cu(nae_ctx* ctx, const StCfg& c, const StView& in, const long long* d_pos, const float* d_fract, const int* d_tile_n,
+                    size_t tiles, long long n_limit, const StOut& out, size_t n_streams)
+{
+    if (tiles == 0 || n_limit <= 0 || n_streams == 0) return NAE_OK;
+    AaParams p;
+    for (int k = 0; k < kAaLen; k++) p.h[k] = c.aa[k];
+    p.j0 = 0; p.j1 = 0;
+    const CuFuse cu{d_pos, d_fract, d_tile_n, n_limit};
+    for (size_t s0 = 0; s0 < n_streams; s0 += 65535) {
+        const unsigned ns = (unsigned)((n_streams - s0 < 65535) ? n_streams - s0 : 65535);
+        StView vin = in;
+        vin.base += (long long)s0 * in.ss;
+        StOut vout = out;
+        vout.base += (long long)s0 * out.ss;
+        if (c.ch == 2)
+            NAE_KLAUNCH(ctx, "st_aa_cu_kernel", (st_aa_kernel<2, true>), dim3((unsigned)tiles, ns), dim3(256), 0, ctx->stream,
+                        dview(vin, 2), p, dout(vout, 2), cu);
+        else
+            NAE_KLAUNCH(ctx, "st_aa_cu_kernel", (st_aa_kernel<1, true>), dim3((unsigned)tiles, ns), dim3(256), 0, ctx->stream,
+                        dview(vin, 1), p, dout(vout, 1), cu);
+    }
+    return nae_check(ctx, hipGetLastError(), "st_aa_cu_kernel");
+}
+
+// first cubic output of every fused tile: tile t covers filter outputs [1021 t, 1021 t + 1024)
+void st_tile_starts(const CuTable& tab, long long n_limit, std::vector<int>& tile_n)
+{
+    tile_n.clear();
+    if (n_limit <= 0) return;
+    const long long last_pos = tab.pos[(size_t)n_limit - 1];
+    const size_t tiles = (size_t)(last_pos / kAaTileFused) + 1;
+    size_t n = 0;
+    for (size_t t = 0; t <= tiles; t++) {
+        const long long lo = (long long)t * kAaTileFused;
+        while (n < (size_t)n_limit && tab.pos[n] < lo) n++;
+        tile_n.push_back((int)n);
+    }
 }
 
 // ------------------------------------------------------------------ CU: cubic transposer

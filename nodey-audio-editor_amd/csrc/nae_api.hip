@@ -190,6 +190,7 @@ int nae_ctx_create(int device, nae_ctx** out)
     ctx->dbg_rs_single = getenv("NAE_RS_SINGLE") != nullptr;
     ctx->dbg_no_mix_fuse = getenv("NAE_NO_MIX_FUSE") != nullptr;
     if (const char* e = getenv("NAE_TD_NC")) ctx->dbg_td_nc = atoi(e);
+    ctx->dbg_st_unfused = getenv("NAE_ST_UNFUSED") != nullptr;
     ctx->dbg_pv_lockstep = 8;
     if (const char* e = getenv("NAE_PV_LOCKSTEP")) {
         const int n = atoi(e);

@@ -30,6 +30,7 @@ struct nae_ctx {
     bool dbg_pv_highocc = false;     // NAE_PV_HIGHOCC: force the 4-waves-per-SIMD synth build (A/B only)
     bool dbg_pv_lowocc = false;      // NAE_PV_LOWOCC: force the 2-waves-per-SIMD synth build
     int dbg_pv_lockstep = 8;         // NAE_PV_LOCKSTEP=N: workgroup barrier every N frames in the pipelined synth kernel (0: never)
+    bool dbg_st_unfused = false;     // NAE_ST_UNFUSED: WSOLA chain runs filter and cubic stage as separate launches
     int dbg_td_nc = 0;               // NAE_TD_NC=1|2|4: candidates per thread of the WSOLA search (0: by batch size)
     bool dbg_pv_no_pipeline = false; // NAE_PV_NO_PIPELINE: use the non-pipelined synth kernel for long tiles
     bool dbg_no_mix_fuse = false;    // NAE_NO_MIX_FUSE: graph4 runs mix and transposer as separate launches

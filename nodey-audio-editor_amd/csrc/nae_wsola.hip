@@ -6,6 +6,7 @@
 #include <math.h>
 #include <new>
 #include <string.h>
+#include <vector>
 
 namespace nae {
 
@@ -190,6 +191,8 @@ struct nae_wsola_cache {
     long long* d_pos = nullptr;
     float* d_fract = nullptr;
     size_t tab_cap = 0;
+    int* d_tile_n = nullptr;        // first cubic output of every fused filter+cubic tile (orders 0 and 1)
+    size_t tile_cap = 0, n_tiles = 0;
     void* ws_a = nullptr; size_t ws_a_bytes = 0;
     void* ws_b = nullptr; size_t ws_b_bytes = 0;
 };
@@ -206,6 +209,7 @@ void nae_wsola_cache_free(nae_ctx* ctx)
     if (!c) return;
     if (c->d_pos) (void)hipFree(c->d_pos);
     if (c->d_fract) (void)hipFree(c->d_fract);
+    if (c->d_tile_n) (void)hipFree(c->d_tile_n);
     if (c->ws_a) (void)hipFree(c->ws_a);
     if (c->ws_b) (void)hipFree(c->ws_b);
     delete c;
@@ -280,6 +284,26 @@ int nae_wsola_block_f32(nae_ctx* ctx, int sample_rate, double rate, double pitch
         }
         rc = upload_cu(ctx, tab, 0, tab.pos.size(), wc->d_pos, wc->d_fract);
         if (rc) return rc;
+        wc->n_tiles = 0;
+        if (wc->cfg.order != 2) {
+            // filter and cubic stage are adjacent: they run as one launch, tile by tile
+            std::vector<int> tile_n;
+            st_tile_starts(tab, wc->cfg.order == 0 ? wc->out_len : s.cu_out, tile_n);
+            if (tile_n.size() > wc->tile_cap) {
+                (void)hipStreamSynchronize(ctx->stream);
+                if (wc->d_tile_n) (void)hipFree(wc->d_tile_n);
+                wc->d_tile_n = nullptr; wc->tile_cap = 0;
+                const size_t cap = tile_n.size() + tile_n.size() / 8 + 64;
+                if (hipMalloc((void**)&wc->d_tile_n, cap * sizeof(int)) != hipSuccess) return nae_fail(ctx, NAE_ERR_NOMEM, "hipMalloc(tile table)");
+                wc->tile_cap = cap;
+            }
+            if (!tile_n.empty()) {
+                hipError_t e = hipMemcpyAsync(wc->d_tile_n, tile_n.data(), tile_n.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+                if (e != hipSuccess) return nae_check(ctx, e, "hipMemcpyAsync(tile table)");
+                wc->n_tiles = tile_n.size() - 1;
+            }
+        }
         wc->sr = sample_rate; wc->ch = ch; wc->rate = rate; wc->pitch = pitch; wc->in_len = in_len;
         wc->valid = true;
     }
@@ -311,12 +335,20 @@ int nae_wsola_block_f32(nae_ctx* ctx, int sample_rate, double rate, double pitch
     switch (cfg.order) {
     case 0:
         rc = st_launch_td(ctx, cfg, v_src, all, o_a, n_streams, nullptr, offsets_dbg, n_offs);
-        if (!rc) rc = st_launch_aa(ctx, cfg, v_a, 0, fin.aa_out, o_b, n_streams);
-        if (!rc) rc = st_launch_cu(ctx, cfg, v_b, wc->d_pos, wc->d_fract, 0, 0, wc->out_len, o_dst, n_streams);
+        if (!rc && !ctx->dbg_st_unfused)
+            rc = st_launch_aa_cu(ctx, cfg, v_a, wc->d_pos, wc->d_fract, wc->d_tile_n, wc->n_tiles, wc->out_len, o_dst, n_streams);
+        else {
+            if (!rc) rc = st_launch_aa(ctx, cfg, v_a, 0, fin.aa_out, o_b, n_streams);
+            if (!rc) rc = st_launch_cu(ctx, cfg, v_b, wc->d_pos, wc->d_fract, 0, 0, wc->out_len, o_dst, n_streams);
+        }
         break;
     case 1:
-        rc = st_launch_aa(ctx, cfg, v_src, 0, fin.aa_out, o_a, n_streams);
-        if (!rc) rc = st_launch_cu(ctx, cfg, v_a, wc->d_pos, wc->d_fract, 0, 0, fin.cu_out, o_b, n_streams);
+        if (!ctx->dbg_st_unfused)
+            rc = st_launch_aa_cu(ctx, cfg, v_src, wc->d_pos, wc->d_fract, wc->d_tile_n, wc->n_tiles, fin.cu_out, o_b, n_streams);
+        else {
+            rc = st_launch_aa(ctx, cfg, v_src, 0, fin.aa_out, o_a, n_streams);
+            if (!rc) rc = st_launch_cu(ctx, cfg, v_a, wc->d_pos, wc->d_fract, 0, 0, fin.cu_out, o_b, n_streams);
+        }
         if (!rc) rc = st_launch_td(ctx, cfg, v_b, all, o_dst, n_streams, nullptr, offsets_dbg, n_offs);
         break;
     default:
