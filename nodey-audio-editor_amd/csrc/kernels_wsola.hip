@@ -407,7 +407,10 @@ struct CuFuse {
 };
 constexpr int kAaTileFused = kAaTile - 3;
 
-template <int CH, bool kCubic>
+// kCubicIn: the cubic transposer fused IN FRONT of the filter (rate < 1): the tile's input frames are cubic outputs
+// cu.pos / cu.fr [jt + u], evaluated from the raw signal while staging (cu.n_limit = number of cubic outputs that
+// exist; beyond it the filter reads zeros); the transposed signal never touches HBM.
+template <int CH, bool kCubic, bool kCubicIn = false>
 __global__ __launch_bounds__(256) void st_aa_kernel(DView in, AaParams p, DOut out, CuFuse cu)
 {
     __shared__ float tile[4 * kAaRow * CH];
@@ -418,7 +421,26 @@ __global__ __launch_bounds__(256) void st_aa_kernel(DView in, AaParams p, DOut o
     const float* sbase = in.v.base + s * in.v.ss;
     float* obase = out.o.base + s * out.o.ss;
     for (int u = tid; u < kAaTile + kAaLen; u += 256) {
-        const Frame<CH> x = ld_frame<CH>(in, sbase, jt + u);
+        Frame<CH> x;
+        if (kCubicIn) {
+            const long long n = jt + u;
+#pragma unroll
+            for (int c = 0; c < CH; c++) x.x[c] = 0.0f;
+            if (n < cu.n_limit) {
+                const long long a = cu.pos[n];
+                const float x2 = cu.fr[n], x1 = x2 * x2, x0 = x1 * x2, x3 = 1.0f;
+                const float y0 = ((-0.5f * x0 + 1.0f * x1) + -0.5f * x2) + 0.0f * x3;
+                const float y1 = ((1.5f * x0 + -2.5f * x1) + 0.0f * x2) + 1.0f * x3;
+                const float y2 = ((-1.5f * x0 + 2.0f * x1) + 0.5f * x2) + 0.0f * x3;
+                const float y3 = ((0.5f * x0 + -0.5f * x1) + 0.0f * x2) + 0.0f * x3;
+                const Frame<CH> p0 = ld_frame<CH>(in, sbase, a), p1 = ld_frame<CH>(in, sbase, a + 1);
+                const Frame<CH> p2 = ld_frame<CH>(in, sbase, a + 2), p3 = ld_frame<CH>(in, sbase, a + 3);
+#pragma unroll
+                for (int c = 0; c < CH; c++) x.x[c] = ((y0 * p0.x[c] + y1 * p1.x[c]) + y2 * p2.x[c]) + y3 * p3.x[c];
+            }
+        } else {
+            x = ld_frame<CH>(in, sbase, jt + u);
+        }
 #pragma unroll
         for (int c = 0; c < CH; c++) tile[((u & 3) * kAaRow + (u >> 2)) * CH + c] = x.x[c];
     }
@@ -556,6 +578,33 @@ int st_launch_aa_cu(nae_ctx* ctx, const StCfg& c, const StView& in, const long l
                         dview(vin, 1), p, dout(vout, 1), cu);
     }
     return nae_check(ctx, hipGetLastError(), "st_aa_cu_kernel");
+}
+
+// cubic + filter in one launch (rate < 1): filter outputs [0, j1) of every stream; the filter's input frame n is the
+// cubic output (d_pos[n], d_fract[n]) of the raw signal `in`, n < n_cu
+int st_launch_cu_aa(nae_ctx* ctx, const StCfg& c, const StView& in, const long long* d_pos, const float* d_fract, long long n_cu,
+                    long long j1, const StOut& out, size_t n_streams)
+{
+    if (j1 <= 0 || n_streams == 0) return NAE_OK;
+    AaParams p;
+    for (int k = 0; k < kAaLen; k++) p.h[k] = c.aa[k];
+    p.j0 = 0; p.j1 = j1;
+    const CuFuse cu{d_pos, d_fract, nullptr, n_cu};
+    const unsigned tiles = (unsigned)((j1 + kAaTile - 1) / kAaTile);
+    for (size_t s0 = 0; s0 < n_streams; s0 += 65535) {
+        const unsigned ns = (unsigned)((n_streams - s0 < 65535) ? n_streams - s0 : 65535);
+        StView vin = in;
+        vin.base += (long long)s0 * in.ss;
+        StOut vout = out;
+        vout.base += (long long)s0 * out.ss;
+        if (c.ch == 2)
+            NAE_KLAUNCH(ctx, "st_cu_aa_kernel", (st_aa_kernel<2, false, true>), dim3(tiles, ns), dim3(256), 0, ctx->stream, dview(vin, 2),
+                        p, dout(vout, 2), cu);
+        else
+            NAE_KLAUNCH(ctx, "st_cu_aa_kernel", (st_aa_kernel<1, false, true>), dim3(tiles, ns), dim3(256), 0, ctx->stream, dview(vin, 1),
+                        p, dout(vout, 1), cu);
+    }
+    return nae_check(ctx, hipGetLastError(), "st_cu_aa_kernel");
 }
 
 // first cubic output of every fused tile: tile t covers filter outputs [1021 t, 1021 t + 1024)

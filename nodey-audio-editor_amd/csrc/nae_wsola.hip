@@ -352,8 +352,12 @@ int nae_wsola_block_f32(nae_ctx* ctx, int sample_rate, double rate, double pitch
         if (!rc) rc = st_launch_td(ctx, cfg, v_b, all, o_dst, n_streams, nullptr, offsets_dbg, n_offs);
         break;
     default:
-        rc = st_launch_cu(ctx, cfg, v_src, wc->d_pos, wc->d_fract, 0, 0, fin.cu_out, o_a, n_streams);
-        if (!rc) rc = st_launch_aa(ctx, cfg, v_a, 0, fin.aa_out, o_b, n_streams);
+        if (!ctx->dbg_st_unfused)
+            rc = st_launch_cu_aa(ctx, cfg, v_src, wc->d_pos, wc->d_fract, fin.cu_out, fin.aa_out, o_b, n_streams);
+        else {
+            rc = st_launch_cu(ctx, cfg, v_src, wc->d_pos, wc->d_fract, 0, 0, fin.cu_out, o_a, n_streams);
+            if (!rc) rc = st_launch_aa(ctx, cfg, v_a, 0, fin.aa_out, o_b, n_streams);
+        }
         if (!rc) rc = st_launch_td(ctx, cfg, v_b, all, o_dst, n_streams, nullptr, offsets_dbg, n_offs);
         break;
     }

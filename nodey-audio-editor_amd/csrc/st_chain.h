@@ -76,6 +76,8 @@ int st_launch_aa(nae_ctx* ctx, const StCfg& c, const StView& in, long long j0, l
                  size_t n_streams);
 int st_launch_aa_cu(nae_ctx* ctx, const StCfg& c, const StView& in, const long long* d_pos, const float* d_fract, const int* d_tile_n,
                     size_t tiles, long long n_limit, const StOut& out, size_t n_streams);
+int st_launch_cu_aa(nae_ctx* ctx, const StCfg& c, const StView& in, const long long* d_pos, const float* d_fract, long long n_cu,
+                    long long j1, const StOut& out, size_t n_streams);
 void st_tile_starts(const CuTable& tab, long long n_limit, std::vector<int>& tile_n);
 int st_launch_cu(nae_ctx* ctx, const StCfg& c, const StView& in, const long long* d_pos, const float* d_fract,
                  long long tab_origin, long long n0, long long n1, const StOut& out, size_t n_streams);
