@@ -41,6 +41,12 @@ def test_no_cpu_fallback_symbols(nae):
             if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp")):
                 src = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "nae_oracle" not in src and "import orc" not in src and "liboracle" not in src, f
+    # the profiling / A-B helpers under tools/ are not allowed to touch the oracle either (the ones that do live in tests/tools/)
+    for f in os.listdir(os.path.join(ROOT, "tools")):
+        path = os.path.join(ROOT, "tools", f)
+        if os.path.isfile(path):
+            src = open(path, errors="replace").read()
+            assert "import orc" not in src and "nae_oracle" not in src and "oracle/" not in src, f
 
 
 @pytest.mark.parametrize("rate,pitch,L", [(1.0, 2 ** (3 / 12), 48000), (1.5, 1 / 1.5, 48000), (0.5, 1.0, 1000),

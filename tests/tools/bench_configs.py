@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """Time every BASELINE.json config on one MI355X and print a markdown table (profiles/r01_configs.md is its output).
+Lives under tests/ because it checks parity against, and times, the CPU oracle (only tests/, smoke() and bench.py may).
 bench.py remains the contract benchmark (C5); this tool covers C1-C4 and the per-node kernels."""
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np

@@ -1,13 +1,14 @@
 #!/usr/bin/env python3
 """Time the SoundTouch-shaped WSOLA chain (K7 option A) at the C5 per-GPU size: N streams x 10 s stereo.
-   python tools/bench_wsola.py [--streams 1024] [--seconds 10] [--rate 1.0] [--semitones 3] [--check]"""
+Lives under tests/ because --check compares with, and times, the CPU oracle (only tests/, smoke() and bench.py may).
+   python tests/tools/bench_wsola.py [--streams 1024] [--seconds 10] [--rate 1.0] [--semitones 3] [--check]"""
 import argparse
 import json
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
