@@ -177,12 +177,13 @@ def main():
                     "note": "K7 is VALU-issue-bound (FFT + atan2/sincos per bin), not HBM-bound; see DESIGN.md §4 and "
                             "profiles/r01_v6_valu.md (VALUBusy)"}
         if dom == "pv_synth_kernel" and pl.pv_on:
-            # informational: vector-issue utilisation of the vocoder kernel from its static instruction count (ISA of the
-            # shipped build: 1155 VALU instructions per wave per frame, rocprofv3 SQ_INSTS_VALU) against 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz
+            # informational: vector-issue utilisation of the vocoder kernel from its dynamic instruction count (1155 VALU
+            # instructions per wave per frame, rocprofv3 SQ_INSTS_VALU) against the calibrated issue rate of one wave-instruction
+            # per 3.2 cycles per SIMD at 2.4 GHz (tools/ubench/mfma_dft8.hip): 256 CUs x 4 SIMDs x 64 lanes / 3.2 x 2.4 GHz
             frames = n_streams * 2 * pl.frames
             roofline["valu_issue_est"] = {"instr_per_frame_wave": 1155, "frames_per_launch": int(frames),
-                                          "achieved_lane_instr_per_s": frames * 1155 * 64 / avg_s, "peak": 39.3e12,
-                                          "frac": round(frames * 1155 * 64 / avg_s / 39.3e12, 3)}
+                                          "achieved_lane_instr_per_s": frames * 1155 * 64 / avg_s, "peak": 49.2e12,
+                                          "frac": round(frames * 1155 * 64 / avg_s / 49.2e12, 3)}
     chain_gbs = 64.03 * value / world / 1e9              # 24 + 16 + 24.03 B per sample-frame, per GPU
 
     out = {
