@@ -607,6 +607,33 @@ int st_launch_cu_aa(nae_ctx* ctx, const StCfg& c, const StView& in, const long l
     return nae_check(ctx, hipGetLastError(), "st_cu_aa_kernel");
 }
 
+// (position, fraction) of `count` consecutive cubic outputs, continued on the device from the state (pos0, fract0):
+// the library's own recurrence (fract += rate; whole = int(fract); fract -= whole) in IEEE double, so the entries
+// equal the host's bit for bit.  Sequential by nature; used by the streaming handle, whose puts add a few thousand
+// outputs at a time, so that a put never has to wait for a host-to-device copy.
+__global__ void st_cu_table_kernel(long long pos0, double fract0, double rate, long long count, long long* __restrict__ pos,
+                                   float* __restrict__ fr)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    long long p = pos0;
+    double f = fract0;
+    for (long long i = 0; i < count; i++) {
+        pos[i] = p;
+        fr[i] = (float)f;
+        f += rate;
+        const int whole = (int)f;
+        f -= (double)whole;
+        p += whole;
+    }
+}
+
+int st_launch_cu_table(nae_ctx* ctx, long long pos0, double fract0, double rate, long long count, long long* d_pos, float* d_fract)
+{
+    if (count <= 0) return NAE_OK;
+    NAE_KLAUNCH(ctx, "st_cu_table_kernel", st_cu_table_kernel, dim3(1), dim3(64), 0, ctx->stream, pos0, fract0, rate, count, d_pos, d_fract);
+    return nae_check(ctx, hipGetLastError(), "st_cu_table_kernel");
+}
+
 // first cubic output of every fused tile: tile t covers filter outputs [1021 t, 1021 t + 1024)
 void st_tile_starts(const CuTable& tab, long long n_limit, std::vector<int>& tile_n)
 {

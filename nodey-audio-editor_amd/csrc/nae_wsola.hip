@@ -435,7 +435,6 @@ struct nae_wsola {
     nae_ctx* ctx = nullptr;
     StCfg cfg;
     StState st;                  // everything up to this state has been computed on the device
-    CuTable tab;                 // cubic read positions not yet consumed
     long long* d_pos = nullptr;
     float* d_fract = nullptr;
     size_t tab_cap = 0;
@@ -455,25 +454,23 @@ int wsola_run(nae_wsola* h, const StState& before)
     const StCfg& c = h->cfg;
     const StState& now = h->st;
     int rc;
-    // table entries for the new cubic outputs
+    // table entries for the new cubic outputs: generated on the device from the state in front of them (no host copy,
+    // so a put never blocks)
     const long long cu_new = now.cu_out - before.cu_out;
     if (cu_new > 0) {
         if ((size_t)cu_new > h->tab_cap) {
-            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipStreamSynchronize(ctx->stream);     // growth only: the old table may still be in use
             if (h->d_pos) (void)hipFree(h->d_pos);
             if (h->d_fract) (void)hipFree(h->d_fract);
             h->d_pos = nullptr; h->d_fract = nullptr; h->tab_cap = 0;
-            const size_t cap = (size_t)cu_new * 2 + 1024;
+            const size_t cap = (size_t)cu_new * 2 + 4096;
             if (hipMalloc((void**)&h->d_pos, cap * sizeof(long long)) != hipSuccess ||
                 hipMalloc((void**)&h->d_fract, cap * sizeof(float)) != hipSuccess)
                 return nae_fail(ctx, NAE_ERR_NOMEM, "hipMalloc(cubic table)");
             h->tab_cap = cap;
         }
-        hipError_t e = hipMemcpyAsync(h->d_pos, h->tab.pos.data(), (size_t)cu_new * sizeof(long long), hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess)
-            e = hipMemcpyAsync(h->d_fract, h->tab.fract.data(), (size_t)cu_new * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        if (e != hipSuccess) return nae_check(ctx, e, "hipMemcpyAsync(cubic table)");
+        rc = st_launch_cu_table(ctx, before.cu_pos, before.cu_fract, c.rate, cu_new, h->d_pos, h->d_fract);
+        if (rc) return rc;
     }
     AbsFifo* chain[4] = {&h->in, &h->a, &h->b, &h->out};
     const int kinds[3][3] = {{0, 1, 2}, {1, 2, 0}, {2, 1, 0}};   // 0 TD, 1 AA, 2 CU per stage slot
@@ -508,7 +505,6 @@ int wsola_run(nae_wsola* h, const StState& before)
         rc = absfifo_drop(ctx, src, keep_from);
         if (rc) return rc;
     }
-    h->tab.drop_before(now.cu_out);
     return NAE_OK;
 }
 
@@ -553,7 +549,7 @@ static int wsola_append(nae_wsola* h, const float* p, size_t S, bool host)
     h->in.total += (long long)S;
     h->in_real = h->in.total;
     const StState before = h->st;
-    st_sim_put(h->cfg, h->st, (long long)S, &h->tab);
+    st_sim_put(h->cfg, h->st, (long long)S, nullptr);
     return wsola_run(h, before);
 }
 
@@ -565,7 +561,7 @@ int nae_wsola_flush(nae_wsola* h)
     if (!h) return NAE_ERR_INVALID;
     if (h->flushed) return NAE_OK;
     const StState before = h->st;
-    const long long avail = sim_flush(h->cfg, h->st, h->received, &h->tab, nullptr);
+    const long long avail = sim_flush(h->cfg, h->st, h->received, nullptr, nullptr);
     const int rc = wsola_run(h, before);
     if (rc) return rc;
     h->out_limit = h->received + avail;

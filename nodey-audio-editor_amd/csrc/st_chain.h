@@ -78,6 +78,7 @@ int st_launch_aa_cu(nae_ctx* ctx, const StCfg& c, const StView& in, const long l
                     size_t tiles, long long n_limit, const StOut& out, size_t n_streams);
 int st_launch_cu_aa(nae_ctx* ctx, const StCfg& c, const StView& in, const long long* d_pos, const float* d_fract, long long n_cu,
                     long long j1, const StOut& out, size_t n_streams);
+int st_launch_cu_table(nae_ctx* ctx, long long pos0, double fract0, double rate, long long count, long long* d_pos, float* d_fract);
 void st_tile_starts(const CuTable& tab, long long n_limit, std::vector<int>& tile_n);
 int st_launch_cu(nae_ctx* ctx, const StCfg& c, const StView& in, const long long* d_pos, const float* d_fract,
                  long long tab_origin, long long n0, long long n1, const StOut& out, size_t n_streams);
