@@ -74,9 +74,11 @@ struct nae_stretch {
 struct nae_spectrum {
     nae_ctx* ctx;
     int ch;
-    DevBuf pending;      // interleaved samples not yet covered by a complete hop
-    DevBuf out;          // [frames][ch][513]
-    size_t out_read = 0; // frames handed out
+    // ping-pong pairs: the live data always moves into the OTHER buffer of its pair (an in-place forward move would
+    // overlap), and nothing is allocated, freed or waited for once the buffers have grown to their working size
+    DevBuf pending, pending_alt;   // interleaved samples not yet covered by a complete hop
+    DevBuf out, out_alt;           // [frames][ch][513]
+    size_t out_read = 0;           // frames handed out
     size_t out_frames = 0;
 };
 
@@ -553,22 +555,18 @@ int nae_spectrum_put(nae_spectrum* h, const float* interleaved, size_t S)
     const size_t F = nae_spectrum_frames(T);
     if (F == 0) return NAE_OK;
     const size_t rec = (size_t)h->ch * NAE_FFT_BINS;
-    // compact what has been read, then append the new frames
+    // compact what has been read (into the other buffer of the pair), then append the new frames
     if (h->out_read) {
         const size_t keep = (h->out_frames - h->out_read) * rec;
         if (keep) {
-            // overlapping forward move is not safe with memcpy: stage through a fresh buffer only when needed
-            DevBuf nb;
-            rc = devbuf_reserve(ctx, nb, keep + F * rec);
+            h->out_alt.len = 0;
+            rc = devbuf_reserve(ctx, h->out_alt, keep + F * rec);
             if (rc) return rc;
-            e = hipMemcpyAsync(nb.p, h->out.p + h->out_read * rec, keep * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream);
-            if (e != hipSuccess) { devbuf_free(nb); return nae_check(ctx, e, "hipMemcpyAsync(compact)"); }
-            (void)hipStreamSynchronize(ctx->stream);
-            devbuf_free(h->out);
-            h->out = nb;
-            h->out.len = keep;
-        } else
-            h->out.len = 0;
+            e = hipMemcpyAsync(h->out_alt.p, h->out.p + h->out_read * rec, keep * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream);
+            if (e != hipSuccess) return nae_check(ctx, e, "hipMemcpyAsync(compact)");
+            std::swap(h->out, h->out_alt);
+        }
+        h->out.len = keep;
         h->out_frames -= h->out_read;
         h->out_read = 0;
     }
@@ -582,16 +580,14 @@ int nae_spectrum_put(nae_spectrum* h, const float* interleaved, size_t S)
     // keep the samples the next frame still needs: everything from F*hop on
     const size_t drop = F * NAE_HOP * h->ch;
     const size_t tail = h->pending.len - drop;
-    DevBuf nb;
-    rc = devbuf_reserve(ctx, nb, tail ? tail : 1);
+    h->pending_alt.len = 0;
+    rc = devbuf_reserve(ctx, h->pending_alt, tail ? tail : 1);
     if (rc) return rc;
     if (tail) {
-        e = hipMemcpyAsync(nb.p, h->pending.p + drop, tail * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream);
-        if (e != hipSuccess) { devbuf_free(nb); return nae_check(ctx, e, "hipMemcpyAsync(tail)"); }
+        e = hipMemcpyAsync(h->pending_alt.p, h->pending.p + drop, tail * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream);
+        if (e != hipSuccess) return nae_check(ctx, e, "hipMemcpyAsync(tail)");
     }
-    (void)hipStreamSynchronize(ctx->stream);
-    devbuf_free(h->pending);
-    h->pending = nb;
+    std::swap(h->pending, h->pending_alt);
     h->pending.len = tail;
     return NAE_OK;
 }
@@ -617,7 +613,9 @@ int nae_spectrum_destroy(nae_spectrum* h)
     if (!h) return NAE_OK;
     (void)hipStreamSynchronize(h->ctx->stream);
     devbuf_free(h->pending);
+    devbuf_free(h->pending_alt);
     devbuf_free(h->out);
+    devbuf_free(h->out_alt);
     delete h;
     return NAE_OK;
 }
