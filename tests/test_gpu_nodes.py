@@ -370,3 +370,76 @@ def test_non_finite_input_does_not_fault(ctx, nae):
     ctx.sync()
     assert ctx.poll() == 1
     d_x.free(); d_y.free()
+
+
+def _place(rng, n_streams, S, ch, layout):
+    """a random nae_sig layout: returns (host buffer size in floats, Sig builder, index array [s][c][i] -> element)"""
+    pad_e = int(rng.integers(0, 4))                       # misalign the base by 0..3 floats
+    if layout == "interleaved":
+        fs = ch + int(rng.integers(0, 3))                 # frames may be padded
+        cs = 1
+        span = S * fs
+    elif layout == "planar":
+        fs = 1
+        cs = S + int(rng.integers(0, 5))
+        span = ch * cs
+    else:                                                 # "strided": arbitrary non-overlapping strides
+        fs = int(rng.integers(1, 4)) * ch + int(rng.integers(0, 2))
+        cs = 1 if fs >= ch else S * fs
+        span = S * fs + ch
+    ss = span + int(rng.integers(0, 7))
+    idx = (np.arange(n_streams)[:, None, None] * ss + np.arange(ch)[None, :, None] * cs + np.arange(S)[None, None, :] * fs) + pad_e
+    return pad_e + n_streams * ss + 8, (pad_e, ss, cs, fs), idx
+
+
+def test_random_signal_layouts(ctx, nae):
+    """K2/K1/K3 through every kernel path the views can select (16-byte fast paths, interleaved<->planar, flat, generic
+    strided), with misaligned bases, padded strides and odd lengths; expected values by plain numpy indexing"""
+    rng = np.random.default_rng(20260104)
+    for case in range(36):
+        n_streams = int(rng.integers(1, 6))
+        S = int(rng.choice([1, 2, 3, 7, 64, 255, 256, 1000, 4099]))
+        ch = int(rng.integers(1, 3))
+        lay_src, lay_dst = rng.choice(["interleaved", "planar", "strided"], 2)
+        aligned = case % 3 == 0                           # every third case: clean layouts, so the fast paths run too
+        if aligned:
+            lay_src, lay_dst = rng.choice(["interleaved", "planar"], 2)
+        n_src, (pe_s, ss_s, cs_s, fs_s), idx_s = _place(rng, n_streams, S, ch, lay_src)
+        n_dst, (pe_d, ss_d, cs_d, fs_d), idx_d = _place(rng, n_streams, S, ch, lay_dst)
+        if aligned:
+            S = (S + 3) & ~3
+            n_src, (pe_s, ss_s, cs_s, fs_s), idx_s = (n_streams * S * ch, (0, S * ch, 1 if lay_src == "interleaved" else S, ch if lay_src == "interleaved" else 1), None)
+            n_dst, (pe_d, ss_d, cs_d, fs_d), idx_d = (n_streams * S * ch, (0, S * ch, 1 if lay_dst == "interleaved" else S, ch if lay_dst == "interleaved" else 1), None)
+            mk = lambda ss, cs, fs: np.arange(n_streams)[:, None, None] * ss + np.arange(ch)[None, :, None] * cs + np.arange(S)[None, None, :] * fs
+            idx_s, idx_d = mk(ss_s, cs_s, fs_s), mk(ss_d, cs_d, fs_d)
+        src = rng.uniform(-1, 1, n_src).astype(np.float32)
+        d_src, d_dst = ctx.array(src), ctx.array(np.full(n_dst, 7.0, np.float32))
+        s_sig = nae.Sig(d_src.at(pe_s), ss_s, cs_s, fs_s)
+        d_sig = nae.Sig(d_dst.at(pe_d), ss_d, cs_d, fs_d)
+        vol = float(np.float32(rng.uniform(0, 2)))
+        # gain (copy is gain with volume 1: checked on a few cases)
+        if case % 4 == 0:
+            ctx.copy_sig(s_sig, d_sig, S, ch, n_streams)
+            want_vals = src[idx_s]
+        else:
+            ctx.gain_sig(s_sig, d_sig, S, ch, n_streams, vol)
+            want_vals = (src[idx_s] * np.float32(vol)).astype(np.float32)
+        got = d_dst.download()
+        want = np.full(n_dst, 7.0, np.float32)
+        want[idx_d] = want_vals
+        assert np.array_equal(got, want), (case, lay_src, lay_dst, n_streams, S, ch)          # and nothing outside the view is touched
+        # 2-input mix of the same source with itself shifted by one stream's worth of data (stereo only)
+        if ch == 2:
+            src2 = rng.uniform(-1, 1, n_src).astype(np.float32)
+            d_src2 = ctx.array(src2)
+            s2_sig = nae.Sig(d_src2.at(pe_s), ss_s, cs_s, fs_s)
+            d_dst.upload(np.full(n_dst, 7.0, np.float32))
+            v = [float(np.float32(rng.uniform(0, 1))), float(np.float32(rng.uniform(0, 1)))]
+            ctx.amix_sig([s_sig, s2_sig], v, d_sig, S, n_streams)
+            acc = (np.float32(0.0) + src[idx_s] * np.float32(v[0])).astype(np.float32)
+            acc = (acc + (src2[idx_s] * np.float32(v[1])).astype(np.float32)).astype(np.float32)
+            want = np.full(n_dst, 7.0, np.float32)
+            want[idx_d] = acc
+            assert np.array_equal(d_dst.download(), want), ("amix", case, lay_src, lay_dst, n_streams, S)
+            d_src2.free()
+        d_src.free(); d_dst.free()
