@@ -336,3 +336,47 @@ def test_streaming_handles(ctx, nae):
     d_x.free()
     allf = np.concatenate(frames)
     assert np.array_equal(allf, gpu_spectrum(ctx, nae, x, ch)[0])
+
+
+def test_k7_k8_odd_layouts_equal_clean_layouts(ctx, nae):
+    """misaligned bases and padded strides select the non-vectorised load / store paths of the STFT kernels and of the
+    transposer; the arithmetic is the same, so the results must equal the clean-layout results bit for bit"""
+    rng = np.random.default_rng(7)
+    n_streams, L, ch = 3, 9000, 2
+    x = orc.fill_uniform(n_streams * L * ch, 91)
+    for rate, pitch in ((1.0, 2 ** (3 / 12)), (1.0, 2 ** (-4 / 12)), (1.3, 1.0)):
+        clean, pl = gpu_stretch(ctx, nae, x, ch, rate, pitch, n_streams)
+        clean = clean.reshape(n_streams, pl.out_len, ch)
+        for planar_in, planar_out in ((False, False), (True, False), (False, True)):
+            pe_s, pe_d = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+            if planar_in:
+                cs_s, fs_s = L + 3, 1
+                ss_s = ch * cs_s + 5
+            else:
+                cs_s, fs_s = 1, ch + 1
+                ss_s = L * fs_s + 5
+            if planar_out:
+                cs_d, fs_d = pl.out_len + 1, 1
+                ss_d = ch * cs_d + 3
+            else:
+                cs_d, fs_d = 1, ch
+                ss_d = pl.out_len * ch + 1
+            src = np.zeros(pe_s + n_streams * ss_s + 8, np.float32)
+            xs = x.reshape(n_streams, L, ch)
+            idx_s = np.arange(n_streams)[:, None, None] * ss_s + np.arange(L)[None, :, None] * fs_s + np.arange(ch)[None, None, :] * cs_s + pe_s
+            src[idx_s] = xs
+            d_src, d_dst = ctx.array(src), ctx.array(np.full(pe_d + n_streams * ss_d + 8, 5.0, np.float32))
+            ctx.stretch_block(rate, pitch, nae.Sig(d_src.at(pe_s), ss_s, cs_s, fs_s), L, ch, n_streams, nae.Sig(d_dst.at(pe_d), ss_d, cs_d, fs_d))
+            got = d_dst.download()
+            idx_d = np.arange(n_streams)[:, None, None] * ss_d + np.arange(pl.out_len)[None, :, None] * fs_d + np.arange(ch)[None, None, :] * cs_d + pe_d
+            assert np.array_equal(got[idx_d].view(np.uint32), clean.view(np.uint32)), (rate, pitch, planar_in, planar_out)
+            mask = np.ones(got.size, bool)
+            mask[idx_d] = False
+            assert np.all(got[mask] == 5.0)                          # nothing outside the view is written
+            # spectrum of the odd-layout source equals the spectrum of the clean one
+            F = ctx.spectrum_frames(L)
+            d_o = ctx.empty(n_streams * F * ch * 513)
+            ctx.spectrum_block(nae.Sig(d_src.at(pe_s), ss_s, cs_s, fs_s), L, ch, n_streams, d_o.ptr, F * ch * 513)
+            ref = gpu_spectrum(ctx, nae, x, ch, n_streams)
+            assert np.array_equal(d_o.download().reshape(ref.shape).view(np.uint32), ref.view(np.uint32))
+            d_src.free(); d_dst.free(); d_o.free()
