@@ -198,3 +198,28 @@ def test_committed_golden(ctx, nae, golden, name):
     y, offs, _ = gpu_wsola(ctx, nae, x, int(ch), int(sr), float(rate), float(pitch), want_offsets=True)
     assert np.array_equal(y[0].view(np.uint32), g[name].view(np.uint32))
     assert np.array_equal(offs[0], g[name + "_offsets"][: offs.shape[1]])
+
+
+def test_odd_layouts_equal_clean_layouts(ctx, nae):
+    """misaligned bases, padded frame / stream strides and planar destinations select the scalar access paths of the
+    three kernels; results must equal the clean-layout results bit for bit"""
+    sr, ch, L, n_streams = 48000, 2, 30000, 5
+    x = orc.fill_uniform(n_streams * L * ch, 12)
+    for rate, pitch in ((1.0, 2 ** (3 / 12)), (1.0, 0.8), (1.25, 0.8)):
+        clean, pl = gpu_wsola(ctx, nae, x, ch, sr, rate, pitch, n_streams)
+        clean = clean.reshape(n_streams, pl.out_len, ch)
+        for (cs_s, fs_s), (cs_d, fs_d), pe in (((1, 3), (1, 2), 1), ((L + 1, 1), (pl.out_len + 3, 1), 3), ((1, 2), (1, 5), 1)):
+            ss_s = (L * fs_s if cs_s == 1 else ch * cs_s) + 7
+            ss_d = (pl.out_len * fs_d if cs_d == 1 else ch * cs_d) + 3
+            src = np.zeros(pe + n_streams * ss_s + 8, np.float32)
+            idx_s = np.arange(n_streams)[:, None, None] * ss_s + np.arange(L)[None, :, None] * fs_s + np.arange(ch)[None, None, :] * cs_s + pe
+            src[idx_s] = x.reshape(n_streams, L, ch)
+            d_src, d_dst = ctx.array(src), ctx.array(np.full(pe + n_streams * ss_d + 8, 5.0, np.float32))
+            ctx.wsola_block(sr, rate, pitch, nae.Sig(d_src.at(pe), ss_s, cs_s, fs_s), L, ch, n_streams, nae.Sig(d_dst.at(pe), ss_d, cs_d, fs_d))
+            got = d_dst.download()
+            idx_d = np.arange(n_streams)[:, None, None] * ss_d + np.arange(pl.out_len)[None, :, None] * fs_d + np.arange(ch)[None, None, :] * cs_d + pe
+            assert np.array_equal(got[idx_d].view(np.uint32), clean.view(np.uint32)), (rate, pitch, cs_s, fs_s, cs_d, fs_d)
+            mask = np.ones(got.size, bool)
+            mask[idx_d] = False
+            assert np.all(got[mask] == 5.0)
+            d_src.free(); d_dst.free()
