@@ -2,10 +2,11 @@
 """bench.py — BASELINE.json's headline metric on MI355X.
 
 One "step" = one pass of the 4-node graph  input -> mix(2) -> pitch(+3 semitones) -> FFT spectrum  over every
-stream resident on this GPU (BASELINE.json configs[4] / SURVEY.md §8d C5: 1024 independent 48 kHz stereo f32
-streams of 10 s, the second mix input shared by all streams).  Streams shard across GPUs with no data-path
-collective (weak scaling: every rank owns `--streams` streams); the shared source buffer is broadcast once over
-RCCL at setup.  Inputs are resident in HBM before the timed region.
+stream of the job (BASELINE.json configs[4] / SURVEY.md §8d C5: 1024 independent 48 kHz stereo f32 streams of 10 s,
+the second mix input shared by all streams).  The job is FIXED at `--total-streams` (default 1024) and sharded over
+the GPUs — strong scaling, rank r owns streams [r*T/N, (r+1)*T/N) — with no data-path collective; the shared source
+buffer is broadcast once over RCCL at setup.  (`--streams N` instead gives every rank N streams: weak scaling.)
+Inputs are resident in HBM before the timed region.
 
     python bench.py                       # 1 GPU, defaults
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -32,7 +33,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--streams", type=int, default=1024, help="streams per GPU (C5: 1024)")
+    ap.add_argument("--total-streams", type=int, default=1024, help="streams of the whole job, sharded over the GPUs (C5: 1024; strong scaling)")
+    ap.add_argument("--streams", type=int, default=None, help="weak scaling instead: this many streams on EVERY GPU")
+    ap.add_argument("--sustain-seconds", type=float, default=0.0, help="also report ms per step over a back-to-back run of at least this long")
     ap.add_argument("--seconds", type=float, default=10.0, help="length of every stream at 48 kHz (C5: 10 s)")
     ap.add_argument("--cpu-streams", type=int, default=128, help="streams the CPU-oracle baseline is timed on")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -70,7 +73,15 @@ def main():
     nae = naeload.load()
     from nodey_audio_editor_amd import shard
     ctx = nae.Context(local_rank)
-    n_streams, S = a.streams, int(round(a.seconds * 48000))
+    S = int(round(a.seconds * 48000))
+    weak = a.streams is not None
+    if weak:
+        first_stream, last_stream = shard.stream_range(rank, a.streams)
+    else:
+        first_stream, last_stream = shard.strong_range(rank, world, a.total_streams)
+    n_streams = last_stream - first_stream              # streams resident on THIS GPU
+    if n_streams < 1:
+        raise SystemExit(f"rank {rank}: no stream to process ({a.total_streams} streams over {world} GPUs)")
     pitch = 2.0 ** (a.semitones / 12.0)
     pl = ctx.stretch_plan(a.rate, pitch, S)
     F = ctx.spectrum_frames(pl.out_len)
@@ -80,7 +91,6 @@ def main():
     d_mix = ctx.empty(n_streams * S * 2)
     d_pitch = ctx.empty(n_streams * pl.out_len * 2)
     d_spec = ctx.empty(n_streams * F * 2 * BINS)
-    first_stream, _ = shard.stream_range(rank, n_streams)   # stream s of the job lives on rank s // n_streams
     ctx.fill_uniform(d_a.ptr, S * 2, S * 2, n_streams, first_stream, 0)
     if dist is not None:
         # shared second mix input: generated on rank 0, broadcast over RCCL/xGMI (the only collective)
@@ -140,7 +150,8 @@ def main():
             dist.destroy_process_group()
         return
 
-    value = shard.job_throughput(world, n_streams, S, a.steps, elapsed)
+    job_streams = world * n_streams if weak else a.total_streams
+    value = shard.job_throughput(world, n_streams, S, a.steps, elapsed) if weak else shard.job_throughput_total(job_streams, S, a.steps, elapsed)
 
     # ---- roofline of the dominant kernel: algorithmic (compulsory) bytes of that launch / its mean duration
     sf = n_streams * S                                   # sample-frames one launch covers on this GPU
@@ -184,17 +195,17 @@ def main():
             roofline["valu_issue_est"] = {"instr_per_frame_wave": 1155, "frames_per_launch": int(frames),
                                           "achieved_lane_instr_per_s": frames * 1155 * 64 / avg_s, "peak": 49.2e12,
                                           "frac": round(frames * 1155 * 64 / avg_s / 49.2e12, 3)}
-    chain_gbs = 64.03 * value / world / 1e9              # 24 + 16 + 24.03 B per sample-frame, per GPU
+    chain_gbs = 64.03 * (n_streams * S * a.steps / elapsed) / 1e9   # 24 + 16 + 24.03 B per sample-frame, rank 0's GPU
 
     out = {
         "metric": "stereo f32 sample-frames/s through the 4-node graph input->mix(2)->pitch->FFT-spectrum @48 kHz",
         "value": value, "unit": "sample-frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "C5 (BASELINE.json configs[4]): independent 48 kHz stereo f32 streams through "
                                f"input->mix(2)->pitch({a.semitones:+g} semitones, rate {a.rate:g}, phase vocoder N=1024 hop=256)"
                                "->spectrum(N=1024 hop=256)",
-                   "streams_per_gpu": n_streams, "seconds_per_stream": a.seconds, "sample_frames_per_stream": S,
+                   "job_streams": job_streams, "streams_on_rank0": n_streams, "seconds_per_stream": a.seconds, "sample_frames_per_stream": S,
                    "shared_second_input": True, "parallelism": f"streams sharded over {world} GPU(s), no data-path collective",
                    "device": ctx.name()},
         "roofline": roofline,

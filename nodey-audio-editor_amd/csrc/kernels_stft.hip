@@ -12,20 +12,16 @@
 //
 // Replaces: SoundTouch behind /root/reference/src/processor/audio-velocity.cpp:369-428 (K7; algorithm differs,
 // see DESIGN.md §3) and the FFTW-based spectrum the reference declares but never implements (K8).
-#include "nae_internal.h"
-#include "stft_device.h"
+#include "stft_common.h"
 #include <stdlib.h>
 
 namespace nae {
 
 constexpr int kWaves = 8;                        // waves per workgroup
 constexpr int kThreads = kWaves * 64;
-constexpr int kT1024Pad = kPhasePad;             // 513 entries, padded to 520
 constexpr size_t kLdsTables = NAE_FFT_N * sizeof(float) + kT1024Pad * sizeof(cf) + 64 * sizeof(cf);
 constexpr size_t kLdsPerWaveSpec = kScratchCf * sizeof(cf);
 constexpr size_t kLdsPerWavePv = kScratchCf * sizeof(cf) + kRingFloats * sizeof(float);
-
-struct Tables { const cf* w512; const cf* t1024; const float* hann; };
 
 struct LdsLayout {
     float* hann;
@@ -34,10 +30,6 @@ struct LdsLayout {
     cf* scratch;   // this wave's
     float* ring;   // this wave's (pv only)
 };
-
-// wave index as a SCALAR: hipcc cannot prove threadIdx.x >> 6 wave-uniform, and everything derived from it
-// (stream / tile / frame addresses) would otherwise be carried in VGPRs with 64-bit vector address math
-__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
 template <bool kRing>
 __device__ __forceinline__ LdsLayout lds_setup(const Tables& tb)
@@ -56,8 +48,6 @@ __device__ __forceinline__ LdsLayout lds_setup(const Tables& tb)
     __syncthreads();
     return L;
 }
-
-struct SigViewD { const float* base; long long ss, cs, fs; };
 
 // ------------------------------------------------------------------------------------------------ K8
 // one wave per (stream, frame); channels looped so an interleaved source is fetched by one wave
@@ -161,30 +151,100 @@ __global__ __launch_bounds__(kThreads, NAE_SPEC_OCC) void spectrum_stereo_kernel
     }
 }
 
-// ------------------------------------------------------------------------------------------------ K7
-struct PvParams {
-    long long ha_q24;
-    long long in_len;     // valid input sample-frames per stream
-    long long frames;     // F
-    long long mid_len;    // PV-stage output samples wanted
-    int d0;
-    unsigned r_q24_0, r_q24_1;
-    int ch;
-    int tile;             // frames (== output hop blocks) per tile
-    int n_tiles;
-    long long f_origin;   // first frame / output block of tile 0 (0 in block mode; > 0 when a stream is continued)
-    long long f_stop;     // one past the last frame / block this launch is responsible for
-    int skip_last;        // pass 1 only: the last tile's sum is not needed (nothing is carried on behind it)
-    int lockstep;         // synth: workgroup barrier every `lockstep` frames (power of two; 0 = never) so the channel waves
-                          // of a stream store their halves of an interleaved line close together: the halves then merge
-                          // in L2 instead of leaving for HBM as two partial writes
-};
+// Interleaved-stereo spectrum, low-register form (<= 80 VGPRs, 6 waves per SIMD; see fft512_pad in stft_device.h for
+// why waves per SIMD matter more than instructions on gfx950).  A wave walks kSpecChunk frames of one stream; per frame
+// one 16-byte load per lane and row fetches (L0 R0 L1 R1) for both channels, the two windowed channel copies are made at
+// once (the raw samples die there: the 75 % overlap of consecutive frames is re-read through L1/L2, not kept in
+// registers), then each channel runs FFT -> split -> magnitude.  Bit-identical output to spectrum_stereo_kernel.
+constexpr int kSpec2Waves = 12;                         // 768 threads; two workgroups per CU = 24 waves
+constexpr int kSpec2Threads = 64 * kSpec2Waves;
+constexpr size_t kSpec2LdsTables = NAE_FFT_N * sizeof(float) + (kT1024Pad + 64 + kTwaCf) * sizeof(cf);
+constexpr size_t kSpec2Lds = kSpec2LdsTables + kSpec2Waves * kPadScratchCf * sizeof(cf);
+static_assert(2 * kSpec2Lds <= 160 * 1024, "two workgroups per CU");
 
-__device__ __forceinline__ long long frame_start(const PvParams& p, long long f)
+__global__ __launch_bounds__(kSpec2Threads, 6) void spectrum_stereo2_kernel(const float* __restrict__ src, long long src_ss, long long n_frames,
+                                                                          long long chunks_per_stream, long long n_items,
+                                                                          float* __restrict__ dst, long long dst_ss, Tables tb)
 {
-    return (((f - 1) * p.ha_q24 + (1ll << (NAE_HA_FRAC_BITS - 1))) >> NAE_HA_FRAC_BITS) - NAE_FFT_N / 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* hann = reinterpret_cast<float*>(smem);
+    cf* t1024 = reinterpret_cast<cf*>(smem + NAE_FFT_N * sizeof(float));
+    cf* w64 = t1024 + kT1024Pad;
+    cf* twa = w64 + 64;
+    for (int i = threadIdx.x; i < NAE_FFT_N; i += kSpec2Threads) hann[i] = tb.hann[i];
+    for (int i = threadIdx.x; i < NAE_FFT_BINS; i += kSpec2Threads) t1024[i] = tb.t1024[i];
+    if (threadIdx.x < 64) w64[threadIdx.x] = tb.w512[8 * (threadIdx.x >> 3) * (threadIdx.x & 7)];
+    fill_twa(twa, tb.w512, threadIdx.x, kSpec2Threads);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const long long item = (long long)blockIdx.x * kSpec2Waves + wave_id();
+    if (item >= n_items) return;
+    cf* scratch = reinterpret_cast<cf*>(smem + kSpec2LdsTables) + wave_id() * kPadScratchCf;
+    const FftLds L = make_fft_lds(scratch, twa, w64, lane);
+    const float2* hw = reinterpret_cast<const float2*>(hann) + lane;
+    const cf* tsp = t1024 + lane;
+    const long long s = item / chunks_per_stream;
+    const long long f0 = (item % chunks_per_stream) * kSpecChunk;
+    long long f1 = f0 + kSpecChunk;
+    if (f1 > n_frames) f1 = n_frames;
+    const float* sbase = src + s * src_ss + 4 * lane;              // frames lie fully inside [0, T) by construction
+    float* obase = dst + s * dst_ss;
+#pragma unroll 1
+    for (long long f = f0; f < f1; f++) {
+        const float* base = sbase + 2 * (f * NAE_HOP);
+        cf v0[8], v1[8];
+        {
+            float4 raw[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) raw[j] = *reinterpret_cast<const float4*>(base + 256 * j);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float2 w = hw[64 * j];
+                v0[j] = cf{raw[j].x * w.x, raw[j].z * w.y};
+                v1[j] = cf{raw[j].y * w.x, raw[j].w * w.y};
+            }
+        }
+        // buffer stores: scalar descriptor of the frame's two spectra + one lane offset (no 64-bit per-lane addresses)
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(obase + (f * 2) * NAE_FFT_BINS, 0, -1, 0x00020000);
+#pragma unroll 1
+        for (int c = 0; c < 2; c++) {
+            if (c == 1) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) v0[j] = v1[j];
+            }
+            fft512_pad(v0, L);
+#pragma unroll
+            for (int r = 0; r < 8; r++) L.nat[64 * r] = v0[r];
+            if (lane == 0) scratch[512] = v0[0];
+            wave_lds_sync();
+            // r2c split delivering 2 X (no 1/2 factors): |2 X|^2 = 4 |X|^2 and sqrt(4 a) = 2 sqrt(a) are exact scalings, so
+            // 0.5 * sqrt(.) is the canonical magnitude bit for bit (for |X| above ~1e-18, where no square is denormal)
+            const cf z0 = scratch[0];
+            cf nyq;
+            {
+                const cf E = cf{z0.x + z0.x, z0.y - z0.y};
+                const cf O = cf{z0.x - z0.x, z0.y + z0.y};
+                const cf P = cmul_tw(O, t1024[512]);
+                nyq = cf{E.x + P.y, E.y - P.x};
+            }
+            const int cofs = c * NAE_FFT_BINS * 4;
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const cf A = v0[r], B = L.mir[448 - 64 * r];
+                const cf E = cf{A.x + B.x, A.y - B.y};
+                const cf O = cf{A.x - B.x, A.y + B.y};
+                const cf P = cmul_tw(O, tsp[64 * r]);
+                const cf X = cf{E.x + P.y, E.y - P.x};
+                const float m = 0.5f * sqrt_rn(X.x * X.x + X.y * X.y);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m), rs, 4 * lane + 256 * r, cofs, 0);
+            }
+            if (lane == 0) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(0.5f * sqrt_rn(nyq.x * nyq.x + nyq.y * nyq.y)), rs, 2048, cofs, 0);
+            wave_lds_sync();
+        }
+    }
 }
 
+// ------------------------------------------------------------------------------------------------ K7
 // analysis of one frame: windowed load, FFT, split.  X[k] for k = kl+64r in v, X[512] returned.
 template <bool kUnit>
 __device__ __forceinline__ cf analyse(cf (&v)[8], const ChanView& in, long long s, const LdsLayout& L,
@@ -193,41 +253,6 @@ __device__ __forceinline__ cf analyse(cf (&v)[8], const ChanView& in, long long 
     load_frame_windowed<kUnit>(v, in, s, L.hann, lane);
     fft512_fwd(v, L.scratch, tw, lane);
     return rfft_split<true>(v, L.scratch, L.t1024, lane);   // 2 X: only phases are taken from it (pass 1)
-}
-
-// NAE_ABL_* macros: timing-only ablation builds for tools/ab.sh (wrong results by construction; never shipped)
-__device__ __forceinline__ void phases_of(const cf (&v)[8], cf nyq, uint32_t (&qa)[9])
-{
-#ifdef NAE_ABL_NO_ATAN2
-#pragma unroll
-    for (int r = 0; r < 8; r++) qa[r] = __float_as_uint(v[r].y) ^ __float_as_uint(v[r].x);
-    qa[8] = __float_as_uint(nyq.y) ^ __float_as_uint(nyq.x);
-#else
-#pragma unroll
-    for (int r = 0; r < 8; r++) qa[r] = atan2_q32(v[r].y, v[r].x);
-    qa[8] = (nyq.x < 0.0f) ? 0x80000000u : 0u;     // bin N/2 of a real signal is real
-#endif
-}
-
-// phase increment of one hop for this lane's 9 bins (integer, exact)
-__device__ __forceinline__ void phase_inc(const uint32_t (&qa)[9], const uint32_t (&qp)[9], uint32_t (&acc)[9],
-                                          int kl, unsigned d, unsigned R)
-{
-#ifdef NAE_ABL_NO_PHASEINC
-#pragma unroll
-    for (int r = 0; r < 9; r++) acc[r] += qa[r] - qp[r] + d + R;
-    return;
-#endif
-#pragma unroll
-    for (int r = 0; r < 9; r++) {
-        const unsigned k = (r < 8) ? (unsigned)(kl + 64 * r) : 512u;
-        const uint32_t e = ((k * d) & (NAE_FFT_N - 1)) << 22;
-        const int32_t dw = (int32_t)(qa[r] - qp[r] - e);
-        const uint32_t adv = ((k * NAE_HOP) & (NAE_FFT_N - 1)) << 22;
-        // R <= 2^26 (d >= 64), so it is a positive int32: one signed 32x32->64 multiply-add (v_mad_i64_i32)
-        const long long scaled = ((long long)dw * (long long)(int32_t)R + (1ll << (NAE_R_FRAC_BITS - 1))) >> NAE_R_FRAC_BITS;
-        acc[r] += adv + (uint32_t)scaled;
-    }
 }
 
 // pass 1: per-tile sum of phase increments.  sums[(sc * n_tiles + tile) * 520 + k]
@@ -315,8 +340,6 @@ __global__ void pv_scan_kernel(uint32_t* __restrict__ sums, long long n_sc, int 
     }
     if (carry_out) carry_out[sc * kT1024Pad + k] = run;
 }
-
-struct OutViewD { float* base; long long ss, cs, fs; };
 
 // pass 3: synthesis of one tile of output hop blocks [tile*T, (tile+1)*T)
 template <bool kUnit, int kOcc>
@@ -1046,6 +1069,11 @@ int nae_launch_spectrum(nae_ctx* ctx, const nae_sig* src, size_t T, int ch, size
     if (stereo_fast) {
         const long long chunks = ((long long)F + kSpecChunk - 1) / kSpecChunk;
         const long long citems = chunks * (long long)n_streams;
+        if (!ctx->dbg_spec_old)
+            NAE_KLAUNCH(ctx, "spectrum_kernel", spectrum_stereo2_kernel, dim3((unsigned)((citems + kSpec2Waves - 1) / kSpec2Waves)), dim3(kSpec2Threads),
+                        kSpec2Lds, ctx->stream, static_cast<const float*>(src->base), (long long)src->stream_stride, (long long)F, chunks, citems,
+                        dst, (long long)dst_stream_stride, tb);
+        else
         NAE_KLAUNCH(ctx, "spectrum_kernel", spectrum_stereo_kernel, dim3((unsigned)((citems + kWaves - 1) / kWaves)), dim3(kThreads),
                     lds, ctx->stream, static_cast<const float*>(src->base), (long long)src->stream_stride, (long long)T,
                     (long long)F, chunks, citems, dst, (long long)dst_stream_stride, tb);
@@ -1139,6 +1167,8 @@ int nae_launch_pv_synth(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig*
     Tables tb{ctx->d_w512, ctx->d_t1024, ctx->d_hann};
     const unsigned grid = (unsigned)((items + kWaves - 1) / kWaves);
     const size_t lds = kLdsTables + kWaves * kLdsPerWavePv;
+    if (!ctx->dbg_pv_no_pipe)
+        return nae_launch_pv_pipe(ctx, p, to_view(src), (long long)n_streams * ch, phase_ws, to_out(out), src->frame_stride == 1);
     // few long tiles (<= one 512-thread workgroup per CU): the 2-waves-per-SIMD build has 256 VGPRs and no spills
     const bool low_occ = (grid <= 256 || ctx->dbg_pv_lowocc) && !ctx->dbg_pv_highocc;
 #define NAE_SYNTH(U, O) NAE_KLAUNCH(ctx, "pv_synth_kernel", (pv_synth_kernel<U, O>), dim3(grid), dim3(kThreads), lds, ctx->stream, \

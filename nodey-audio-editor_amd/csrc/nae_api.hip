@@ -187,6 +187,7 @@ int nae_ctx_create(int device, nae_ctx** out)
     ctx->dbg_pv_lowocc = getenv("NAE_PV_LOWOCC") != nullptr;
     ctx->dbg_pv_highocc = getenv("NAE_PV_HIGHOCC") != nullptr;
     ctx->dbg_pv_no_pipeline = getenv("NAE_PV_NO_PIPELINE") != nullptr;
+    ctx->dbg_pv_no_pipe = getenv("NAE_PV_NO_PIPE") != nullptr;
     ctx->dbg_rs_single = getenv("NAE_RS_SINGLE") != nullptr;
     ctx->dbg_no_mix_fuse = getenv("NAE_NO_MIX_FUSE") != nullptr;
     if (const char* e = getenv("NAE_TD_NC")) ctx->dbg_td_nc = atoi(e);
@@ -198,6 +199,7 @@ int nae_ctx_create(int device, nae_ctx** out)
     }
     ctx->dbg_rs_direct = getenv("NAE_RS_DIRECT") != nullptr;
     ctx->dbg_spec_generic = getenv("NAE_SPEC_GENERIC") != nullptr;
+    ctx->dbg_spec_old = getenv("NAE_SPEC_OLD") != nullptr;
     std::vector<nae::cf> w512, t1024;
     std::vector<float> hann;
     build_tables(w512, t1024, hann);

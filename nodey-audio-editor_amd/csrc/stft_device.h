@@ -163,6 +163,97 @@ __device__ __forceinline__ void fft512_fwd2(cf (&a)[8], cf (&b)[8], cf* __restri
     dft8_fwd(b);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Low-register form of the same FFT (identical arithmetic, so identical bits): every LDS access is a per-lane base
+// register plus an IMMEDIATE offset — no swizzle arithmetic, no hoisted address registers — and the pass-A twiddles
+// come from an LDS table instead of 14 VGPRs.  Conflict-freedom comes from padding instead of XOR swizzles:
+//   T1  element u1[q][l]     at  72 q + l          (write: lane l, imm 72 q;  read: lane (m, qq) at 72 qq + m, imm 8 j)
+//   T2  element u2[q][p][m]  at  q + 8 p + 66 m    (write: lane (m, qq) at qq + 66 m, imm 8 p;  read: lane, imm 66 j)
+// ds_write_b64 is serviced in 16-lane groups over 32 banks, ds_read_b64 in 32-lane groups over 64 banks
+// (MI355X_MICROARCH.md §LDS): 72 = 8 mod 32 and 66 = 2 mod 16 make each group hit distinct banks.
+// Scratch: 576 complex (4608 B) per wave; natural order [lane + 64 r] (+ one entry at 512) uses the same area.
+// What it buys: ~80 VGPRs instead of 239, i.e. 6 waves per SIMD instead of 2 — and on gfx950 the vector issue rate
+// of a SIMD grows with resident waves up to 8 (profiles/r02_valu_issue.md: one wave alone issues one instruction per
+// 4.5-5 cycles, eight waves together one per 1.0-1.4).
+constexpr int kPadScratchCf = 576;
+constexpr int kTwaCf = 7 * 64;                   // LDS table W512^(lane q), q = 1..7, laid out [q-1][lane]
+
+// 8-byte LDS accesses that hipcc must not pair up: its load/store optimizer turns two ds_read_b64 off one base register
+// into one ds_read2_b64 / ds_read2st64_b64, which on gfx950 moves the same 16 bytes per lane in twice the LDS time
+// (profiles/r02_valu_issue.md: 20.3 vs 2 x 5.15 cycles per SIMD at 8 waves).  A volatile access is left alone.
+typedef __attribute__((address_space(3))) volatile unsigned long long lds_vu64;
+__device__ __forceinline__ cf lds_ld(const cf* p)
+{
+    const unsigned long long u = *(const lds_vu64*)(p);
+    return cf{__uint_as_float((unsigned)u), __uint_as_float((unsigned)(u >> 32))};
+}
+__device__ __forceinline__ void lds_st(cf* p, cf v)
+{
+    *(lds_vu64*)(p) = (unsigned long long)__float_as_uint(v.x) | ((unsigned long long)__float_as_uint(v.y) << 32);
+}
+
+struct FftLds {
+    cf* nat;         // scratch + lane                        natural [64 r], T1 write [72 q], T2 read [66 j]
+    cf* t1r;         // scratch + 72 (lane >> 3) + (lane & 7) T1 read  [8 j]
+    cf* t2w;         // scratch + (lane >> 3) + 66 (lane & 7) T2 write [8 p]
+    cf* mir;         // scratch + 64 - lane                   mirror   [448 - 64 r]  == natural[512 - lane - 64 r]
+    const cf* twa;   // twa table + lane                      [64 (q - 1)]
+    const cf* twb;   // w64 table + 8 (lane & 7)              [p]
+};
+
+__device__ __forceinline__ FftLds make_fft_lds(cf* scratch, const cf* twa, const cf* w64, int lane)
+{
+    FftLds L;
+    L.nat = scratch + lane;
+    L.t1r = scratch + 72 * (lane >> 3) + (lane & 7);
+    L.t2w = scratch + (lane >> 3) + 66 * (lane & 7);
+    L.mir = scratch + 64 - lane;
+    L.twa = twa + lane;
+    L.twb = w64 + 8 * (lane & 7);
+    return L;
+}
+
+// fills the pass-A twiddle table (one workgroup-wide call before the first barrier)
+__device__ __forceinline__ void fill_twa(cf* twa, const cf* __restrict__ w512, int tid, int n_threads)
+{
+    for (int i = tid; i < kTwaCf; i += n_threads) twa[i] = w512[(i & 63) * ((i >> 6) + 1)];
+}
+
+// pass A (registers + the read-only twiddle table): may run while another wave still reads this wave's scratch
+__device__ __forceinline__ void fft512_pad_a(cf (&v)[8], const FftLds& L)
+{
+    dft8_fwd(v);
+#pragma unroll
+    for (int q = 1; q < 8; q++) v[q] = cmul_tw(v[q], lds_ld(L.twa + 64 * (q - 1)));
+}
+
+// transposes, passes B and C
+__device__ __forceinline__ void fft512_pad_bc(cf (&v)[8], const FftLds& L)
+{
+#pragma unroll
+    for (int q = 0; q < 8; q++) lds_st(L.nat + 72 * q, v[q]);
+    wave_lds_sync();
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = lds_ld(L.t1r + 8 * j);
+    wave_lds_sync();
+    dft8_fwd(v);
+#pragma unroll
+    for (int p = 1; p < 8; p++) v[p] = cmul_tw(v[p], lds_ld(L.twb + p));
+#pragma unroll
+    for (int p = 0; p < 8; p++) lds_st(L.t2w + 8 * p, v[p]);
+    wave_lds_sync();
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = lds_ld(L.nat + 66 * j);
+    wave_lds_sync();
+    dft8_fwd(v);
+}
+
+__device__ __forceinline__ void fft512_pad(cf (&v)[8], const FftLds& L)
+{
+    fft512_pad_a(v, L);
+    fft512_pad_bc(v, L);
+}
+
 // canonical r2c split.  in: v[r] = Z[kl + 64 r].  out: v[r] = X[kl + 64 r]; returns X[512] (meaningful on lane 0).
 // Leaves Z in natural order in scratch[0..511].
 // kTwice: deliver 2 X instead of X (the two 1/2 factors are skipped; a factor 2 is exact in every operation below, so

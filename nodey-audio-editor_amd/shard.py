@@ -1,7 +1,12 @@
-"""Multi-GPU sharding of independent streams: stream s of the job lives on rank s // per_rank (weak
-scaling: every rank owns the same number of streams), there is no data-path collective, and the only exchange is the
-one-shot broadcast of the shared source buffer from rank 0 at setup (RCCL over xGMI on GPUs, gloo in the CPU tests).
-torch.distributed is plumbing only; nothing here computes audio."""
+"""Multi-GPU sharding of independent streams.  Two job shapes:
+
+* strong scaling (BASELINE.json configs[4], the default of bench.py): the job is `total` streams, rank r owns the
+  contiguous slice [r*total//world, (r+1)*total//world) — sizes differ by at most one stream;
+* weak scaling (`bench.py --streams N`): every rank owns N streams, stream s of the job lives on rank s // N.
+
+Either way there is no data-path collective: streams share nothing (/root/reference/src/infra/runner.cpp:35-50, one
+product per link).  The only exchange is the one-shot broadcast of the shared source buffer from rank 0 at setup
+(RCCL over xGMI on GPUs, gloo in the CPU tests).  torch.distributed is plumbing only; nothing here computes audio."""
 from __future__ import annotations
 
 import os
@@ -15,6 +20,13 @@ def env_rank_world() -> Tuple[int, int, int]:
 def stream_range(rank: int, per_rank: int) -> Tuple[int, int]:
     """global stream ids [first, last) owned by `rank`"""
     return rank * per_rank, (rank + 1) * per_rank
+
+
+def strong_range(rank: int, world: int, total: int) -> Tuple[int, int]:
+    """global stream ids [first, last) of `rank` when a job of `total` streams is cut into `world` contiguous slices"""
+    if world < 1 or not (0 <= rank < world) or total < 0:
+        raise ValueError(f"bad shard request rank={rank} world={world} total={total}")
+    return rank * total // world, (rank + 1) * total // world
 
 
 def stream_seed(stream: int, input_index: int = 0) -> int:
@@ -45,5 +57,10 @@ def max_over_ranks(dist, seconds: float, device=None) -> float:
 
 
 def job_throughput(world: int, per_rank_streams: int, frames_per_stream: int, steps: int, elapsed_s: float) -> float:
-    """whole-job sample-frames/s: all ranks' units over the slowest rank's time"""
+    """weak mode, whole-job sample-frames/s: all ranks' units over the slowest rank's time"""
     return world * per_rank_streams * frames_per_stream * steps / elapsed_s
+
+
+def job_throughput_total(total_streams: int, frames_per_stream: int, steps: int, elapsed_s: float) -> float:
+    """strong mode: the job's `total_streams` (however they were cut) over the slowest rank's time"""
+    return total_streams * frames_per_stream * steps / elapsed_s
