@@ -36,6 +36,22 @@ static_assert(2 * kPipeLds <= 160 * 1024, "two workgroups per CU");
 // the frame prefetch of R1 and the block stores of R3 must not be drained twice per step)
 __device__ __forceinline__ void pipe_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+#ifdef NAE_PIPE_STAMPS
+// diagnostic build only (tools/pipe_stamps.sh): s_memtime around both barriers of steps 200..207, workgroup 0
+__device__ unsigned long long g_pipe_stamps[12 * 8 * 4];
+__device__ unsigned long long g_pipe_total[4 * 64];      // {cycles, realtime ticks, steps, xcc/hw id} of wave 0 of 64 sampled workgroups
+#define PIPE_BARRIER(t, which)                                                                                              \
+    do {                                                                                                                    \
+        const bool st_ = blockIdx.x == 0 && (t) >= 200 && (t) < 208;                                                        \
+        const unsigned long long a_ = __builtin_amdgcn_s_memtime();                                                         \
+        pipe_barrier();                                                                                                     \
+        const unsigned long long b_ = __builtin_amdgcn_s_memtime();                                                         \
+        if (st_ && lane == 0) { g_pipe_stamps[(wave * 8 + ((t) - 200)) * 4 + 2 * (which)] = a_; g_pipe_stamps[(wave * 8 + ((t) - 200)) * 4 + 2 * (which) + 1] = b_; } \
+    } while (0)
+#else
+#define PIPE_BARRIER(t, which) pipe_barrier()
+#endif
+
 template <bool kUnit>
 __global__ __launch_bounds__(kPipeThreads, 6) void pv_pipe_kernel(SigViewD src, PvParams p, long long n_sc,
                                                                  const uint32_t* __restrict__ base_phase, OutViewD out, Tables tb)
@@ -84,6 +100,9 @@ __global__ __launch_bounds__(kPipeThreads, 6) void pv_pipe_kernel(SigViewD src, 
     const int n = (int)(f_end - f_first);
     if (n <= 0) return;
 
+#ifdef NAE_PIPE_STAMPS
+    const unsigned long long tot_c0 = __builtin_amdgcn_s_memtime(), tot_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     if (role == 0) {
         // ------------------------------------------------------------------------------------------ R1: analysis FFT
         ChanView in{src.base + s_idx * src.ss + c * src.cs, src.fs, p.in_len};
@@ -93,7 +112,7 @@ __global__ __launch_bounds__(kPipeThreads, 6) void pv_pipe_kernel(SigViewD src, 
         load_frame_raw<kUnit>(nxt, in, frame_start(p, f_first), lane);
 #pragma unroll 1
         for (int t = 0; t < n + 2; t++) {
-            pipe_barrier();                                   // A
+            PIPE_BARRIER(t, 0);                               // A
             if (t < n) {
                 // register-only part while R2 reads Z of frame t-1 out of this wave's scratch
 #pragma unroll
@@ -104,7 +123,7 @@ __global__ __launch_bounds__(kPipeThreads, 6) void pv_pipe_kernel(SigViewD src, 
                 if (t + 1 < n) load_frame_raw<kUnit>(nxt, in, frame_start(p, f_first + t + 1), lane);
                 fft512_pad_a(va, L);
             }
-            pipe_barrier();                                   // B: R2 holds X of frame t-1 in registers
+            PIPE_BARRIER(t, 1);                               // B: R2 holds X of frame t-1 in registers
             if (t < n) {
                 fft512_pad_bc(va, L);
 #pragma unroll
@@ -112,6 +131,13 @@ __global__ __launch_bounds__(kPipeThreads, 6) void pv_pipe_kernel(SigViewD src, 
                 if (lane == 0) S1[512] = va[0];               // so that the mirror of bin 0 is read like any other
             }
         }
+#ifdef NAE_PIPE_STAMPS
+        if (wave == 0 && lane == 0 && (blockIdx.x & 7) == 0 && (blockIdx.x >> 3) < 64) {
+            unsigned long long* o = g_pipe_total + 4 * (blockIdx.x >> 3);
+            o[0] = __builtin_amdgcn_s_memtime() - tot_c0; o[1] = __builtin_amdgcn_s_memrealtime() - tot_r0; o[2] = n + 2;
+            o[3] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        }
+#endif
     } else if (role == 1) {
         // ------------------------------------------------------------------------------------------ R2: phases
         const cf* Zn = S1 + lane;
@@ -131,7 +157,7 @@ __global__ __launch_bounds__(kPipeThreads, 6) void pv_pipe_kernel(SigViewD src, 
         for (int t = 0; t < n + 2; t++) {
             const bool active = (t >= 1) && (t <= n);
             const long long f = f_first + t - 1;
-            pipe_barrier();                                   // A: Z of frame f is complete
+            PIPE_BARRIER(t, 0);                               // A: Z of frame f is complete
             cf va[8], nyq{0.0f, 0.0f};
             if (active) {
                 cf vb[8];
@@ -155,7 +181,7 @@ __global__ __launch_bounds__(kPipeThreads, 6) void pv_pipe_kernel(SigViewD src, 
                     va[r] = cf{E.x + P.y, E.y - P.x};
                 }
             }
-            pipe_barrier();                                   // B: R1 may overwrite its scratch
+            PIPE_BARRIER(t, 1);                               // B: R1 may overwrite its scratch
             if (active) {
                 const long long s = frame_start(p, f);
                 uint32_t qa[9];
@@ -211,7 +237,7 @@ __global__ __launch_bounds__(kPipeThreads, 6) void pv_pipe_kernel(SigViewD src, 
         for (int t = 0; t < n + 2; t++) {
             const long long fz = f_first + t - 2;
             const bool active = (t >= 2) && (fz >= b0);
-            pipe_barrier();                                   // A: Y of frame fz is complete
+            PIPE_BARRIER(t, 0);                               // A: Y of frame fz is complete
             cf zs[8];
             if (active) {
                 // c2r pre-twiddle into FFT input layout, conjugated (inverse = conj(FFT(conj Z)) / 512); 2E, 2D: see kGain
@@ -225,7 +251,7 @@ __global__ __launch_bounds__(kPipeThreads, 6) void pv_pipe_kernel(SigViewD src, 
                     zs[r] = cf{E.x - Q.y, -(E.y + Q.x)};
                 }
             }
-            pipe_barrier();                                   // B: R2 may overwrite Y
+            PIPE_BARRIER(t, 1);                               // B: R2 may overwrite Y
             if (active) {
                 fft512_pad(zs, L);
                 // zs[r] = conj(z[n]) * 512 (x 4), n = lane + 64 r  ->  time samples 2n, 2n+1, windowed
@@ -277,6 +303,11 @@ __global__ __launch_bounds__(kPipeThreads, 6) void pv_pipe_kernel(SigViewD src, 
 } // namespace nae
 
 using namespace nae;
+
+#ifdef NAE_PIPE_STAMPS
+extern "C" int nae_debug_read_pipe_stamps(unsigned long long* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_pipe_stamps), sizeof(unsigned long long) * 12 * 8 * 4); }
+extern "C" int nae_debug_read_pipe_total(unsigned long long* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_pipe_total), sizeof(unsigned long long) * 4 * 64); }
+#endif
 
 int nae_launch_pv_pipe(nae_ctx* ctx, const PvParams& p, const SigViewD& src, long long n_sc, const uint32_t* phase_ws,
                        const OutViewD& out, bool unit_stride)

@@ -4,10 +4,9 @@
 //   * one wavefront = one (stream, channel, tile of frames); a 512-thread workgroup is 8 independent waves
 //     that only share the read-only Hann / split-twiddle tables in LDS (one __syncthreads after the table
 //     fill, none afterwards).
-//   * per wave LDS: 4.5 KiB FFT scratch + 4 KiB overlap-add ring  -> 2 workgroups (16 waves) per CU.
 //   * the phase accumulator is Q0.32 integer, so the time recurrence of the vocoder is an exact prefix sum:
 //     pass 1 (pv_phase_kernel) reduces each tile's phase increments, pass 2 (pv_scan_kernel) scans tiles,
-//     pass 3 (pv_synth_kernel) recomputes the tile with the right starting phase and overlap-adds in LDS.
+//     pass 3 (kernels_pvpipe.hip) recomputes the tile with the right starting phase and overlap-adds in registers.
 //     HBM traffic stays at the algorithmic 4 B in + 4 B out per sample per channel (+ one re-read in pass 1).
 //
 // Replaces: SoundTouch behind /root/reference/src/processor/audio-velocity.cpp:369-428 (K7; algorithm differs,
@@ -21,17 +20,14 @@ constexpr int kWaves = 8;                        // waves per workgroup
 constexpr int kThreads = kWaves * 64;
 constexpr size_t kLdsTables = NAE_FFT_N * sizeof(float) + kT1024Pad * sizeof(cf) + 64 * sizeof(cf);
 constexpr size_t kLdsPerWaveSpec = kScratchCf * sizeof(cf);
-constexpr size_t kLdsPerWavePv = kScratchCf * sizeof(cf) + kRingFloats * sizeof(float);
 
 struct LdsLayout {
     float* hann;
     cf* t1024;
     cf* w64;       // [m][p] = W512^(8 m p)
     cf* scratch;   // this wave's
-    float* ring;   // this wave's (pv only)
 };
 
-template <bool kRing>
 __device__ __forceinline__ LdsLayout lds_setup(const Tables& tb)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -39,9 +35,7 @@ __device__ __forceinline__ LdsLayout lds_setup(const Tables& tb)
     L.hann = reinterpret_cast<float*>(smem);
     L.t1024 = reinterpret_cast<cf*>(smem + NAE_FFT_N * sizeof(float));
     L.w64 = L.t1024 + kT1024Pad;
-    unsigned char* wave_base = smem + kLdsTables + wave_id() * (kRing ? kLdsPerWavePv : kLdsPerWaveSpec);
-    L.scratch = reinterpret_cast<cf*>(wave_base);
-    L.ring = reinterpret_cast<float*>(wave_base + kScratchCf * sizeof(cf));
+    L.scratch = reinterpret_cast<cf*>(smem + kLdsTables + wave_id() * kLdsPerWaveSpec);
     for (int i = threadIdx.x; i < NAE_FFT_N; i += kThreads) L.hann[i] = tb.hann[i];
     for (int i = threadIdx.x; i < NAE_FFT_BINS; i += kThreads) L.t1024[i] = tb.t1024[i];
     if (threadIdx.x < 64) L.w64[threadIdx.x] = tb.w512[8 * (threadIdx.x >> 3) * (threadIdx.x & 7)];
@@ -56,7 +50,7 @@ __global__ __launch_bounds__(kThreads, 4) void spectrum_kernel(SigViewD src, lon
                                                            long long n_items, float* __restrict__ dst,
                                                            long long dst_ss, Tables tb)
 {
-    LdsLayout L = lds_setup<false>(tb);
+    LdsLayout L = lds_setup(tb);
     const int lane = threadIdx.x & 63;
     const long long item = (long long)blockIdx.x * kWaves + wave_id();
     if (item >= n_items) return;
@@ -82,26 +76,15 @@ __global__ __launch_bounds__(kThreads, 4) void spectrum_kernel(SigViewD src, lon
 // A wave walks kSpecChunk consecutive frames of one stream, so the table fill and the twiddle loads of the
 // workgroup are amortised over 8 x kSpecChunk frames.
 constexpr int kSpecChunk = 32;
-#ifdef NAE_ABL_FAST_SQRT
-#define NAE_SPEC_SQRT(x) __builtin_amdgcn_sqrtf(x)
-#else
-#define NAE_SPEC_SQRT(x) sqrt_rn(x)              // correctly rounded: spectrum output is bit-identical to the oracle
-#endif
 // Consecutive frames overlap by 768 of 1024 sample-frames = 6 of the 8 register rows of the FFT input layout
 // (pair index n = lane + 64 j, hop = 128 pairs = 2 rows), so the raw samples are kept in registers and each new
 // frame loads only its last 2 rows: HBM/L2 read traffic drops from ~3.4x to ~1.1x of the input.
-#ifndef NAE_SPEC_OCC
-#define NAE_SPEC_OCC 4
-#endif
-#ifndef NAE_SPEC_LAUNDER
-#define NAE_SPEC_LAUNDER 1
-#endif
-__global__ __launch_bounds__(kThreads, NAE_SPEC_OCC) void spectrum_stereo_kernel(const float* __restrict__ src, long long src_ss, long long T,
+__global__ __launch_bounds__(kThreads, 4) void spectrum_stereo_kernel(const float* __restrict__ src, long long src_ss, long long T,
                                                                      long long n_frames, long long chunks_per_stream,
                                                                      long long n_items, float* __restrict__ dst,
                                                                      long long dst_ss, Tables tb)
 {
-    LdsLayout L = lds_setup<false>(tb);
+    LdsLayout L = lds_setup(tb);
     const int lane = threadIdx.x & 63;
     const long long item = (long long)blockIdx.x * kWaves + wave_id();
     if (item >= n_items) return;
@@ -139,107 +122,14 @@ __global__ __launch_bounds__(kThreads, NAE_SPEC_OCC) void spectrum_stereo_kernel
 #pragma unroll
                 for (int j = 0; j < 8; j++) v0[j] = v1[j];
             }
-            fft512_fwd<NAE_SPEC_LAUNDER>(v0, L.scratch, tw, lane);
+            fft512_fwd<1>(v0, L.scratch, tw, lane);
             // 2 X from the split; |2 X|^2 = 4 |X|^2 and sqrt(4 a) = 2 sqrt(a) are exact scalings, so 0.5 * sqrt(.) is
             // the canonical magnitude bit for bit (for |X| above ~1e-18, where no square is denormal)
             const cf nyq = rfft_split<true>(v0, L.scratch, L.t1024, lane);
 #pragma unroll
-            for (int r = 0; r < 8; r++) o[lane + 64 * r] = 0.5f * NAE_SPEC_SQRT(v0[r].x * v0[r].x + v0[r].y * v0[r].y);
-            if (lane == 0) o[512] = 0.5f * NAE_SPEC_SQRT(nyq.x * nyq.x + nyq.y * nyq.y);
+            for (int r = 0; r < 8; r++) o[lane + 64 * r] = 0.5f * sqrt_rn(v0[r].x * v0[r].x + v0[r].y * v0[r].y);
+            if (lane == 0) o[512] = 0.5f * sqrt_rn(nyq.x * nyq.x + nyq.y * nyq.y);
             o += NAE_FFT_BINS;
-        }
-    }
-}
-
-// Interleaved-stereo spectrum, low-register form (<= 80 VGPRs, 6 waves per SIMD; see fft512_pad in stft_device.h for
-// why waves per SIMD matter more than instructions on gfx950).  A wave walks kSpecChunk frames of one stream; per frame
-// one 16-byte load per lane and row fetches (L0 R0 L1 R1) for both channels, the two windowed channel copies are made at
-// once (the raw samples die there: the 75 % overlap of consecutive frames is re-read through L1/L2, not kept in
-// registers), then each channel runs FFT -> split -> magnitude.  Bit-identical output to spectrum_stereo_kernel.
-constexpr int kSpec2Waves = 12;                         // 768 threads; two workgroups per CU = 24 waves
-constexpr int kSpec2Threads = 64 * kSpec2Waves;
-constexpr size_t kSpec2LdsTables = NAE_FFT_N * sizeof(float) + (kT1024Pad + 64 + kTwaCf) * sizeof(cf);
-constexpr size_t kSpec2Lds = kSpec2LdsTables + kSpec2Waves * kPadScratchCf * sizeof(cf);
-static_assert(2 * kSpec2Lds <= 160 * 1024, "two workgroups per CU");
-
-__global__ __launch_bounds__(kSpec2Threads, 6) void spectrum_stereo2_kernel(const float* __restrict__ src, long long src_ss, long long n_frames,
-                                                                          long long chunks_per_stream, long long n_items,
-                                                                          float* __restrict__ dst, long long dst_ss, Tables tb)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* hann = reinterpret_cast<float*>(smem);
-    cf* t1024 = reinterpret_cast<cf*>(smem + NAE_FFT_N * sizeof(float));
-    cf* w64 = t1024 + kT1024Pad;
-    cf* twa = w64 + 64;
-    for (int i = threadIdx.x; i < NAE_FFT_N; i += kSpec2Threads) hann[i] = tb.hann[i];
-    for (int i = threadIdx.x; i < NAE_FFT_BINS; i += kSpec2Threads) t1024[i] = tb.t1024[i];
-    if (threadIdx.x < 64) w64[threadIdx.x] = tb.w512[8 * (threadIdx.x >> 3) * (threadIdx.x & 7)];
-    fill_twa(twa, tb.w512, threadIdx.x, kSpec2Threads);
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const long long item = (long long)blockIdx.x * kSpec2Waves + wave_id();
-    if (item >= n_items) return;
-    cf* scratch = reinterpret_cast<cf*>(smem + kSpec2LdsTables) + wave_id() * kPadScratchCf;
-    const FftLds L = make_fft_lds(scratch, twa, w64, lane);
-    const float2* hw = reinterpret_cast<const float2*>(hann) + lane;
-    const cf* tsp = t1024 + lane;
-    const long long s = item / chunks_per_stream;
-    const long long f0 = (item % chunks_per_stream) * kSpecChunk;
-    long long f1 = f0 + kSpecChunk;
-    if (f1 > n_frames) f1 = n_frames;
-    const float* sbase = src + s * src_ss + 4 * lane;              // frames lie fully inside [0, T) by construction
-    float* obase = dst + s * dst_ss;
-#pragma unroll 1
-    for (long long f = f0; f < f1; f++) {
-        const float* base = sbase + 2 * (f * NAE_HOP);
-        cf v0[8], v1[8];
-        {
-            float4 raw[8];
-#pragma unroll
-            for (int j = 0; j < 8; j++) raw[j] = *reinterpret_cast<const float4*>(base + 256 * j);
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const float2 w = hw[64 * j];
-                v0[j] = cf{raw[j].x * w.x, raw[j].z * w.y};
-                v1[j] = cf{raw[j].y * w.x, raw[j].w * w.y};
-            }
-        }
-        // buffer stores: scalar descriptor of the frame's two spectra + one lane offset (no 64-bit per-lane addresses)
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(obase + (f * 2) * NAE_FFT_BINS, 0, -1, 0x00020000);
-#pragma unroll 1
-        for (int c = 0; c < 2; c++) {
-            if (c == 1) {
-#pragma unroll
-                for (int j = 0; j < 8; j++) v0[j] = v1[j];
-            }
-            fft512_pad(v0, L);
-#pragma unroll
-            for (int r = 0; r < 8; r++) L.nat[64 * r] = v0[r];
-            if (lane == 0) scratch[512] = v0[0];
-            wave_lds_sync();
-            // r2c split delivering 2 X (no 1/2 factors): |2 X|^2 = 4 |X|^2 and sqrt(4 a) = 2 sqrt(a) are exact scalings, so
-            // 0.5 * sqrt(.) is the canonical magnitude bit for bit (for |X| above ~1e-18, where no square is denormal)
-            const cf z0 = scratch[0];
-            cf nyq;
-            {
-                const cf E = cf{z0.x + z0.x, z0.y - z0.y};
-                const cf O = cf{z0.x - z0.x, z0.y + z0.y};
-                const cf P = cmul_tw(O, t1024[512]);
-                nyq = cf{E.x + P.y, E.y - P.x};
-            }
-            const int cofs = c * NAE_FFT_BINS * 4;
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-                const cf A = v0[r], B = L.mir[448 - 64 * r];
-                const cf E = cf{A.x + B.x, A.y - B.y};
-                const cf O = cf{A.x - B.x, A.y + B.y};
-                const cf P = cmul_tw(O, tsp[64 * r]);
-                const cf X = cf{E.x + P.y, E.y - P.x};
-                const float m = 0.5f * sqrt_rn(X.x * X.x + X.y * X.y);
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m), rs, 4 * lane + 256 * r, cofs, 0);
-            }
-            if (lane == 0) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(0.5f * sqrt_rn(nyq.x * nyq.x + nyq.y * nyq.y)), rs, 2048, cofs, 0);
-            wave_lds_sync();
         }
     }
 }
@@ -260,7 +150,7 @@ template <bool kUnit>
 __global__ __launch_bounds__(kThreads, 4) void pv_phase_kernel(SigViewD src, PvParams p, long long n_items,
                                                               uint32_t* __restrict__ sums, Tables tb)
 {
-    LdsLayout L = lds_setup<false>(tb);
+    LdsLayout L = lds_setup(tb);
     const int lane = threadIdx.x & 63;
     const long long item = (long long)blockIdx.x * kWaves + wave_id();
     if (item >= n_items) return;
@@ -339,395 +229,6 @@ __global__ void pv_scan_kernel(uint32_t* __restrict__ sums, long long n_sc, int 
         run += v;
     }
     if (carry_out) carry_out[sc * kT1024Pad + k] = run;
-}
-
-// pass 3: synthesis of one tile of output hop blocks [tile*T, (tile+1)*T)
-template <bool kUnit, int kOcc>
-__global__ __launch_bounds__(kThreads, kOcc) void pv_synth_kernel(SigViewD src, PvParams p, long long n_items,
-                                                              const uint32_t* __restrict__ base_phase, OutViewD out,
-                                                              Tables tb)
-{
-    LdsLayout L = lds_setup<true>(tb);
-    const int lane = threadIdx.x & 63;
-    const long long item = (long long)blockIdx.x * kWaves + wave_id();
-    if (item >= n_items) return;
-    const long long sc = item / p.n_tiles;
-    const int tile = (int)(item % p.n_tiles);
-    const long long s_idx = sc / p.ch;
-    const int c = (int)(sc % p.ch);
-    ChanView in{src.base + s_idx * src.ss + c * src.cs, src.fs, p.in_len};
-    float* optr = out.base + s_idx * out.ss + c * out.cs;
-    const bool out_vec = (out.fs == 1) && ((reinterpret_cast<uintptr_t>(optr) & 15) == 0); // wave-uniform
-    FftTw tw;
-    load_fft_tw(tw, tb.w512, L.w64, lane);
-    const int kl = kl_of_lane(lane);
-
-    const long long b0 = p.f_origin + (long long)tile * p.tile; // first output block == first frame of the tile
-    long long b_end = b0 + p.tile;
-    if (b_end > p.f_stop) b_end = p.f_stop;
-    long long f_end = b_end + 3;                            // frames b0 .. b_end+2 feed blocks b0 .. b_end-1
-    if (f_end > p.frames) f_end = p.frames;
-
-    uint32_t qs[9], qp[9];
-    {
-        const uint32_t* bp = base_phase + item * kT1024Pad;
-#pragma unroll
-        for (int r = 0; r < 8; r++) { qs[r] = bp[kl + 64 * r]; qp[r] = 0; }
-        qs[8] = bp[512];
-        qp[8] = 0;
-    }
-    cf v[8];
-    long long s_prev = 0;
-    // Each frame is two half-steps around ONE inlined FFT (a second inlined copy costs ~45 VGPRs):
-    //   half 0: windowed frame -> FFT -> split, phases, phase advance, synthesis spectrum, c2r pre-twiddle
-    //   half 1: conj(Z) -> FFT -> windowed overlap-add, emit the completed hop block
-    // Frame b0-1 (when it exists) only primes qp.
-    // kOcc == 2 (256 VGPRs): software-pipelined input — frame f+1 is fetched while frame f is computed, so the
-    // HBM/L2 latency of the only global read of the loop is never exposed
-    constexpr bool kPrefetch = (kOcc <= 2);
-    // kOcc == 2: the per-lane window and split twiddles live in registers (32 VGPRs) instead of being re-read
-    // from LDS twice per frame; both FFT directions use the same natural index lane + 64 j
-    constexpr bool kRegTab = (kOcc <= 2);
-    cf win[8], tsp[8], tsp_nyq{0.0f, 0.0f};
-    if (kRegTab) {
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const float2 w = *reinterpret_cast<const float2*>(L.hann + 2 * (lane + 64 * j));
-            win[j] = cf{w.x, w.y};
-            tsp[j] = L.t1024[lane + 64 * j];
-        }
-        tsp_nyq = L.t1024[512];
-    }
-    cf nxt[8];
-    const long long f_first = (b0 > 0 ? b0 - 1 : 0);
-    if (kPrefetch && f_first < f_end) load_frame_raw<kUnit>(nxt, in, frame_start(p, f_first), lane);
-#pragma unroll 1
-    for (long long f = f_first; f < f_end; f++) {
-        const long long s = frame_start(p, f);
-        if (kPrefetch) {
-#pragma unroll
-            for (int j = 0; j < 8; j++) v[j] = nxt[j];
-            if (f + 1 < f_end) load_frame_raw<kUnit>(nxt, in, frame_start(p, f + 1), lane);
-            if (kRegTab) {
-#pragma unroll
-                for (int j = 0; j < 8; j++) v[j] = cf{v[j].x * win[j].x, v[j].y * win[j].y};
-            } else
-                apply_window(v, L.hann, lane);
-        } else
-            load_frame_windowed<kUnit>(v, in, s, L.hann, lane);
-#pragma unroll 1
-        for (int half = 0; half < 2; half++) {
-            fft512_fwd<(kOcc > 2 ? 2 : 0)>(v, L.scratch, tw, lane);
-            if (half == 0) {
-                const cf nyq = kRegTab ? rfft_split_reg(v, L.scratch, tsp, tsp_nyq, lane) : rfft_split(v, L.scratch, L.t1024, lane);
-                uint32_t qa[9];
-                phases_of(v, nyq, qa);
-                if (f >= b0) {
-                    if (f == 0) {
-#pragma unroll
-                        for (int r = 0; r < 9; r++) qs[r] += qa[r];
-                    } else {
-                        const unsigned d = (unsigned)(s - s_prev);
-                        const unsigned R = (d == (unsigned)p.d0) ? p.r_q24_0 : p.r_q24_1;
-                        phase_inc(qa, qp, qs, kl, d, R);
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < 9; r++) qp[r] = qa[r];
-                s_prev = s;
-                if (f < b0) break;
-                // ---- synthesis spectrum Y = |X| e^{2 pi i qs}, natural order (tolerance path from here)
-                // |X| e^{i qs} == X e^{i (qs - qa)}: rotate by the phase DIFFERENCE (no sqrt; the 5.5e-8-turn error
-                // of the polynomial arctangent only perturbs the result by ~3e-7 relative — tolerance path)
-#pragma unroll
-                for (int r = 0; r < 8; r++) {
-#ifdef NAE_ABL_NO_ROTATE
-                    cf y{v[r].x + __uint_as_float(qs[r] - qa[r]), v[r].y};
-#else
-                    const float ph = (float)(int32_t)(qs[r] - qa[r]) * (1.0f / 4294967296.0f);
-                    const float c = __builtin_amdgcn_cosf(ph), s = __builtin_amdgcn_sinf(ph);
-                    cf y{__builtin_fmaf(v[r].x, c, -(v[r].y * s)), __builtin_fmaf(v[r].x, s, v[r].y * c)};
-#endif
-                    if (r == 0 && lane == 0) y.y = 0.0f; // c2r ignores Im Y[0]
-                    L.scratch[kl + 64 * r] = y;
-                }
-                if (lane == 0) {
-                    const float ph = (float)(int32_t)(qs[8] - qa[8]) * (1.0f / 4294967296.0f);
-                    const float c = __builtin_amdgcn_cosf(ph), s = __builtin_amdgcn_sinf(ph);
-                    L.scratch[512] = cf{__builtin_fmaf(nyq.x, c, -(nyq.y * s)), 0.0f};
-                }
-                wave_lds_sync();
-                // ---- c2r pre-twiddle into FFT input layout, conjugated (inverse = conj(FFT(conj Z)) / 512)
-#pragma unroll
-                for (int r = 0; r < 8; r++) {
-                    const int k = lane + 64 * r;
-                    const cf Xk = L.scratch[k], Xm = L.scratch[512 - k];
-                    const cf T = kRegTab ? tsp[r] : L.t1024[k];
-                    const cf E{0.5f * (Xk.x + Xm.x), 0.5f * (Xk.y - Xm.y)};
-                    const cf D{0.5f * (Xk.x - Xm.x), 0.5f * (Xk.y + Xm.y)};
-                    const cf Q{__builtin_fmaf(T.x, D.x, T.y * D.y), __builtin_fmaf(T.x, D.y, -(T.y * D.x))};
-                    v[r] = cf{E.x - Q.y, -(E.y + Q.x)};
-                }
-                wave_lds_sync();
-            } else {
-                // v[r] = conj(z[n]) * 512, n = kl + 64 r  ->  time samples 2n, 2n+1
-                // ---- windowed overlap-add into the 4-block ring
-#pragma unroll
-                for (int r = 0; r < 8; r++) {
-                    const int n2 = 2 * (kl + 64 * r);
-                    const float2 w = kRegTab ? float2{win[r].x, win[r].y} : *reinterpret_cast<const float2*>(L.hann + n2);
-                    const float y0 = v[r].x * (1.0f / 512.0f) * w.x;
-                    const float y1 = -v[r].y * (1.0f / 512.0f) * w.y;
-                    const int blk = (int)((f - 3 + (r >> 1)) & 3);
-                    float2* slot = reinterpret_cast<float2*>(L.ring + blk * NAE_HOP + (n2 & (NAE_HOP - 1)));
-                    if ((r >> 1) == 3) {
-                        *slot = float2{y0, y1};            // newest block: first contribution
-                    } else {
-                        float2 a = *slot;
-                        a.x += y0; a.y += y1;
-                        *slot = a;
-                    }
-                }
-                wave_lds_sync();
-                // ---- block f-3 is complete
-                const long long be = f - 3;
-                if (be >= b0 && be < b_end && be * NAE_HOP < p.mid_len) {
-                    const long long m0 = be * NAE_HOP + 4 * lane;
-                    const float4 a = *reinterpret_cast<const float4*>(L.ring + (int)(be & 3) * NAE_HOP + 4 * lane);
-                    const float o0 = a.x * NAE_OLA_GAIN, o1 = a.y * NAE_OLA_GAIN, o2 = a.z * NAE_OLA_GAIN,
-                                o3 = a.w * NAE_OLA_GAIN;
-                    if (out_vec && (be + 1) * NAE_HOP <= p.mid_len) {
-                        *reinterpret_cast<float4*>(optr + m0) = float4{o0, o1, o2, o3};
-                    } else {
-                        if (m0 + 0 < p.mid_len) optr[(m0 + 0) * out.fs] = o0;
-                        if (m0 + 1 < p.mid_len) optr[(m0 + 1) * out.fs] = o1;
-                        if (m0 + 2 < p.mid_len) optr[(m0 + 2) * out.fs] = o2;
-                        if (m0 + 3 < p.mid_len) optr[(m0 + 3) * out.fs] = o3;
-                    }
-                }
-                wave_lds_sync();
-            }
-        }
-    }
-}
-
-// pass 3, software-pipelined form for long tiles at 2 waves per SIMD (256 VGPRs, one workgroup per CU):
-// iteration f runs the ANALYSIS FFT of frame f and the INVERSE FFT of frame f-1 in lockstep (fft512_fwd2), then
-// overlaps frame f's split / phase / rotation / c2r pre-twiddle with frame f-1's overlap-add and block store.
-// Same arithmetic, same summation order, 8 wave syncs per frame instead of 14.
-constexpr size_t kLdsPerWavePv2 = 2 * kScratchCf * sizeof(cf);     // two FFT scratch areas; the overlap-add ring is in registers
-
-template <bool kUnit>
-__global__ __launch_bounds__(kThreads, 2) void pv_synth2_kernel(SigViewD src, PvParams p, long long n_items,
-                                                               const uint32_t* __restrict__ base_phase, OutViewD out,
-                                                               Tables tb)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
-    float* hann = reinterpret_cast<float*>(smem2);
-    cf* t1024 = reinterpret_cast<cf*>(smem2 + NAE_FFT_N * sizeof(float));
-    cf* w64 = t1024 + kT1024Pad;
-    for (int i = threadIdx.x; i < NAE_FFT_N; i += kThreads) hann[i] = tb.hann[i];
-    for (int i = threadIdx.x; i < NAE_FFT_BINS; i += kThreads) t1024[i] = tb.t1024[i];
-    if (threadIdx.x < 64) w64[threadIdx.x] = tb.w512[8 * (threadIdx.x >> 3) * (threadIdx.x & 7)];
-    __syncthreads();
-    unsigned char* wave_base = smem2 + kLdsTables + wave_id() * kLdsPerWavePv2;
-    cf* SA = reinterpret_cast<cf*>(wave_base);
-    cf* SS = SA + kScratchCf;
-
-    const int lane = threadIdx.x & 63;
-    const long long item = (long long)blockIdx.x * kWaves + wave_id();
-    if (item >= n_items) return;
-    const long long sc = item / p.n_tiles;
-    const int tile = (int)(item % p.n_tiles);
-    const long long s_idx = sc / p.ch;
-    const int c = (int)(sc % p.ch);
-    ChanView in{src.base + s_idx * src.ss + c * src.cs, src.fs, p.in_len};
-    float* optr = out.base + s_idx * out.ss + c * out.cs;
-    const bool out_vec = (out.fs == 1) && ((reinterpret_cast<uintptr_t>(optr) & 15) == 0);
-    FftTw tw;
-    load_fft_tw(tw, tb.w512, w64, lane);
-
-    const long long b0 = p.f_origin + (long long)tile * p.tile;
-    long long b_end = b0 + p.tile;
-    if (b_end > p.f_stop) b_end = p.f_stop;
-    long long f_end = b_end + 3;
-    if (f_end > p.frames) f_end = p.frames;
-
-    uint32_t qs[9], qp[9];
-    {
-        const uint32_t* bp = base_phase + item * kT1024Pad;
-#pragma unroll
-        for (int r = 0; r < 8; r++) { qs[r] = bp[lane + 64 * r]; qp[r] = 0; }
-        qs[8] = bp[512];
-        qp[8] = 0;
-    }
-    // wsy = synthesis window with every constant of the tolerance path folded in: 1/512 (inverse FFT), 1/2 (the
-    // halves dropped from the c2r pre-twiddle below), 1/2 (the halves dropped from the analysis split) and 2/3
-    // (overlap-add gain); the sign of the odd sample undoes
-    // the conjugation of the inverse-by-forward FFT
-    cf win[8], wsy[8], tsp[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const float2 w = *reinterpret_cast<const float2*>(hann + 2 * (lane + 64 * j));
-        win[j] = cf{w.x, w.y};
-        wsy[j] = cf{w.x * (NAE_OLA_GAIN / 2048.0f), -w.y * (NAE_OLA_GAIN / 2048.0f)};
-        tsp[j] = t1024[lane + 64 * j];
-    }
-    const cf tsp_nyq = t1024[512];
-
-    // Overlap-add in registers.  Sample n = 2*(lane + 64 r) + {0,1} of a frame falls into hop block r >> 1 at offset
-    // 2*lane + 128*(r & 1) + {0,1}: a lane touches the same 4 offsets of every block, so the 3 open blocks are 12 VGPRs
-    // (the 4th block a frame touches is new).  Block fz-3 is complete once frame fz is in; contributions arrive in
-    // increasing frame order, as in the oracle.  (The LDS ring this replaces cost 14 LDS instructions per frame.)
-    float r0[4] = {0.0f, 0.0f, 0.0f, 0.0f}, r1[4] = {0.0f, 0.0f, 0.0f, 0.0f}, r2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    auto ola_emit = [&](const cf (&z)[8], long long fz) {
-        float y[4][4];
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            y[r >> 1][2 * (r & 1)] = z[r].x * wsy[r].x;
-            y[r >> 1][2 * (r & 1) + 1] = z[r].y * wsy[r].y;
-        }
-        float o[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            o[i] = r0[i] + y[0][i];
-            r0[i] = r1[i] + y[1][i];
-            r1[i] = r2[i] + y[2][i];
-            r2[i] = y[3][i];
-        }
-        const long long be = fz - 3;                         // wave-uniform: block base and pointer stay scalar
-        if (be >= b0 && be < b_end && be * NAE_HOP < p.mid_len) {
-            float* pb = optr + be * NAE_HOP * out.fs;
-            const int fs = (int)out.fs;
-            if ((be + 1) * NAE_HOP <= p.mid_len) {
-                if (out_vec) {
-                    *reinterpret_cast<float2*>(pb + 2 * lane) = float2{o[0], o[1]};
-                    *reinterpret_cast<float2*>(pb + 128 + 2 * lane) = float2{o[2], o[3]};
-                } else {
-                    const int a = 2 * lane * fs, b = (128 + 2 * lane) * fs;
-                    pb[a] = o[0]; pb[a + fs] = o[1]; pb[b] = o[2]; pb[b + fs] = o[3];
-                }
-            } else {
-                const int rem = (int)(p.mid_len - be * NAE_HOP);
-                if (2 * lane + 0 < rem) pb[(2 * lane) * fs] = o[0];
-                if (2 * lane + 1 < rem) pb[(2 * lane + 1) * fs] = o[1];
-                if (128 + 2 * lane < rem) pb[(128 + 2 * lane) * fs] = o[2];
-                if (129 + 2 * lane < rem) pb[(129 + 2 * lane) * fs] = o[3];
-            }
-        }
-    };
-
-    cf va[8], zs[8], nxt[8];
-    bool have = false;          // zs holds the pre-twiddled spectrum of frame fz, waiting for its inverse FFT
-    long long fz = 0, s_prev = 0;
-    const long long f_first = (b0 > 0 ? b0 - 1 : 0);
-    if (f_first < f_end) load_frame_raw<kUnit>(nxt, in, frame_start(p, f_first), lane);
-#pragma unroll 1
-    for (long long f = f_first; f < f_end; f++) {
-        const long long s = frame_start(p, f);
-        if (p.lockstep && (f & (p.lockstep - 1)) == 0) __builtin_amdgcn_s_barrier();   // terminated waves are not counted
-#pragma unroll
-        for (int j = 0; j < 8; j++) va[j] = cf{nxt[j].x * win[j].x, nxt[j].y * win[j].y};
-        if (f + 1 < f_end) load_frame_raw<kUnit>(nxt, in, frame_start(p, f + 1), lane);
-#ifndef NAE_ABL_NO_FFT
-        if (have) fft512_fwd2(va, zs, SA, SS, tw, lane);
-        else fft512_fwd<0>(va, SA, tw, lane);
-#endif
-        // ---- phase P1: split exchange (write Z) | overlap-add of frame fz
-#pragma unroll
-        for (int r = 0; r < 8; r++) SA[lane + 64 * r] = va[r];
-        wave_lds_sync();
-        // ---- phase P2: split (mirror read) -> X | store the completed block of frame fz
-        cf nyq;
-        // (the split below yields 2 X: its halves are folded into wsy — phases are scale-invariant, the magnitude is
-        //  restored by the synthesis window, and a factor 2 is exact in every product on the way)
-        {
-            const cf A = SA[0];
-            const cf E = cf{A.x + A.x, A.y - A.y};
-            const cf O = cf{A.x - A.x, A.y + A.y};
-            const cf P = cmul_tw(O, tsp_nyq);
-            nyq = cf{E.x + P.y, E.y - P.x};
-        }
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const int k = lane + 64 * r;
-            const cf A = va[r];
-#ifdef NAE_ABL_NO_SPLIT
-            const cf B = cf{A.y, A.x};
-#else
-            const cf B = SA[(512 - k) & 511];
-#endif
-            const cf E = cf{A.x + B.x, A.y - B.y};
-            const cf O = cf{A.x - B.x, A.y + B.y};
-            const cf P = cmul_tw(O, tsp[r]);
-            va[r] = cf{E.x + P.y, E.y - P.x};
-        }
-#ifndef NAE_ABL_NO_OLA
-        if (have) ola_emit(zs, fz);
-#else
-        if (have && fz == f_end - 2) ola_emit(zs, fz);
-#endif
-        wave_lds_sync();
-        // ---- phase P3: phases, integer phase advance, rotation -> Y (natural order in SA)
-        uint32_t qa[9];
-        phases_of(va, nyq, qa);
-        if (f >= b0) {
-            if (f == 0) {
-#pragma unroll
-                for (int r = 0; r < 9; r++) qs[r] += qa[r];
-            } else {
-                const unsigned d = (unsigned)(s - s_prev);
-                const unsigned R = (d == (unsigned)p.d0) ? p.r_q24_0 : p.r_q24_1;
-                phase_inc(qa, qp, qs, lane, d, R);
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 9; r++) qp[r] = qa[r];
-        s_prev = s;
-        have = (f >= b0);
-        if (have) {
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-#ifdef NAE_ABL_NO_ROTATE
-                cf y{va[r].x + __uint_as_float(qs[r] - qa[r]), va[r].y};
-#else
-                const float ph = (float)(int32_t)(qs[r] - qa[r]) * (1.0f / 4294967296.0f);
-                const float cs = __builtin_amdgcn_cosf(ph), sn = __builtin_amdgcn_sinf(ph);
-                cf y{__builtin_fmaf(va[r].x, cs, -(va[r].y * sn)), __builtin_fmaf(va[r].x, sn, va[r].y * cs)};
-#endif
-                if (r == 0 && lane == 0) y.y = 0.0f;
-                SA[lane + 64 * r] = y;
-                va[r] = y;                                   // own bin stays in registers; only the mirror bin comes from LDS
-            }
-            if (lane == 0) {
-                const float ph = (float)(int32_t)(qs[8] - qa[8]) * (1.0f / 4294967296.0f);
-                const float cs = __builtin_amdgcn_cosf(ph), sn = __builtin_amdgcn_sinf(ph);
-                SA[512] = cf{__builtin_fmaf(nyq.x, cs, -(nyq.y * sn)), 0.0f};
-            }
-            wave_lds_sync();
-            // ---- phase P4: c2r pre-twiddle -> zs (input of the next iteration's inverse FFT)
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-                const int k = lane + 64 * r;
-#ifdef NAE_ABL_NO_UNSPLIT
-                const cf Xk = va[r], Xm = cf{va[r].y, va[r].x};
-#else
-                const cf Xk = va[r], Xm = SA[512 - k];
-#endif
-                const cf T = tsp[r];
-                const cf E{Xk.x + Xm.x, Xk.y - Xm.y};       // 2E, 2D: the factor 1/2 lives in wsy
-                const cf D{Xk.x - Xm.x, Xk.y + Xm.y};
-                const cf Q{__builtin_fmaf(T.x, D.x, T.y * D.y), __builtin_fmaf(T.x, D.y, -(T.y * D.x))};
-                zs[r] = cf{E.x - Q.y, -(E.y + Q.x)};
-            }
-            fz = f;
-            wave_lds_sync();
-        }
-    }
-    if (have) {   // drain the last synthesised frame
-        fft512_fwd<0>(zs, SS, tw, lane);
-        ola_emit(zs, fz);
-    }
 }
 
 // rate transposer: out[j] = sum_i tab(phase)[i] * v[idx - 7 + i],  pos = j * step (Q32.32)
@@ -1034,9 +535,7 @@ __global__ __launch_bounds__(256) void mix_resample_tile_kernel(MixFuseD f, RsPa
         }
     }
     __syncthreads();
-#ifndef NAE_ABL_NO_TAPS
     rs_apply_stereo<NS>(stab, stage, span_alloc, p, j0, j1, m_lo, out, s0, n_streams);
-#endif
 }
 
 } // namespace nae
@@ -1069,11 +568,6 @@ int nae_launch_spectrum(nae_ctx* ctx, const nae_sig* src, size_t T, int ch, size
     if (stereo_fast) {
         const long long chunks = ((long long)F + kSpecChunk - 1) / kSpecChunk;
         const long long citems = chunks * (long long)n_streams;
-        if (!ctx->dbg_spec_old)
-            NAE_KLAUNCH(ctx, "spectrum_kernel", spectrum_stereo2_kernel, dim3((unsigned)((citems + kSpec2Waves - 1) / kSpec2Waves)), dim3(kSpec2Threads),
-                        kSpec2Lds, ctx->stream, static_cast<const float*>(src->base), (long long)src->stream_stride, (long long)F, chunks, citems,
-                        dst, (long long)dst_stream_stride, tb);
-        else
         NAE_KLAUNCH(ctx, "spectrum_kernel", spectrum_stereo_kernel, dim3((unsigned)((citems + kWaves - 1) / kWaves)), dim3(kThreads),
                     lds, ctx->stream, static_cast<const float*>(src->base), (long long)src->stream_stride, (long long)T,
                     (long long)F, chunks, citems, dst, (long long)dst_stream_stride, tb);
@@ -1104,7 +598,6 @@ static PvParams make_pv_params(const nae_stretch_plan& pl, size_t in_len, int ch
     p.f_stop = p.f_origin + cnt;
     p.n_tiles = (int)((cnt + tile - 1) / tile);
     p.skip_last = 0;
-    p.lockstep = 0;
     return p;
 }
 
@@ -1161,33 +654,8 @@ int nae_launch_pv_synth(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig*
                         size_t n_streams, int tile, const uint32_t* phase_ws, const nae_sig* out,
                         const nae_pv_segment* seg)
 {
-    PvParams p = make_pv_params(*pl, in_len, ch, tile, seg);
-    const long long items = (long long)n_streams * ch * p.n_tiles;
-    if (items == 0) return NAE_OK;
-    Tables tb{ctx->d_w512, ctx->d_t1024, ctx->d_hann};
-    const unsigned grid = (unsigned)((items + kWaves - 1) / kWaves);
-    const size_t lds = kLdsTables + kWaves * kLdsPerWavePv;
-    if (!ctx->dbg_pv_no_pipe)
-        return nae_launch_pv_pipe(ctx, p, to_view(src), (long long)n_streams * ch, phase_ws, to_out(out), src->frame_stride == 1);
-    // few long tiles (<= one 512-thread workgroup per CU): the 2-waves-per-SIMD build has 256 VGPRs and no spills
-    const bool low_occ = (grid <= 256 || ctx->dbg_pv_lowocc) && !ctx->dbg_pv_highocc;
-#define NAE_SYNTH(U, O) NAE_KLAUNCH(ctx, "pv_synth_kernel", (pv_synth_kernel<U, O>), dim3(grid), dim3(kThreads), lds, ctx->stream, \
-                                    to_view(src), p, items, phase_ws, to_out(out), tb)
-    if (low_occ && !ctx->dbg_pv_no_pipeline) {
-        p.lockstep = (ch == 2 && out->frame_stride == 2) ? ctx->dbg_pv_lockstep : 0;
-        const size_t lds2 = kLdsTables + kWaves * kLdsPerWavePv2;
-        if (src->frame_stride == 1)
-            NAE_KLAUNCH(ctx, "pv_synth_kernel", (pv_synth2_kernel<true>), dim3(grid), dim3(kThreads), lds2, ctx->stream, to_view(src),
-                        p, items, phase_ws, to_out(out), tb);
-        else
-            NAE_KLAUNCH(ctx, "pv_synth_kernel", (pv_synth2_kernel<false>), dim3(grid), dim3(kThreads), lds2, ctx->stream, to_view(src),
-                        p, items, phase_ws, to_out(out), tb);
-        return nae_check(ctx, hipGetLastError(), "pv_synth2_kernel");
-    }
-    if (src->frame_stride == 1) { if (low_occ) NAE_SYNTH(true, 2); else NAE_SYNTH(true, 4); }
-    else { if (low_occ) NAE_SYNTH(false, 2); else NAE_SYNTH(false, 4); }
-#undef NAE_SYNTH
-    return nae_check(ctx, hipGetLastError(), "pv_synth_kernel");
+    const PvParams p = make_pv_params(*pl, in_len, ch, tile, seg);
+    return nae_launch_pv_pipe(ctx, p, to_view(src), (long long)n_streams * ch, phase_ws, to_out(out), src->frame_stride == 1);
 }
 
 // outputs [j_begin, j_end)
@@ -1272,4 +740,3 @@ int nae_launch_mix_resample(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_
     return NAE_OK;
 }
 
-size_t nae_lds_bytes_pv(void) { return kLdsTables + kWaves * kLdsPerWavePv; }

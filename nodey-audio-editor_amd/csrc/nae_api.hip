@@ -184,22 +184,12 @@ int nae_ctx_create(int device, nae_ctx** out)
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return NAE_ERR_HIP; }
     ctx->own_stream = true;
     if (const char* t = getenv("NAE_PV_TILE")) ctx->pv_tile = atoi(t) > 0 ? atoi(t) : 0;   // tuning knob (0 = automatic)
-    ctx->dbg_pv_lowocc = getenv("NAE_PV_LOWOCC") != nullptr;
-    ctx->dbg_pv_highocc = getenv("NAE_PV_HIGHOCC") != nullptr;
-    ctx->dbg_pv_no_pipeline = getenv("NAE_PV_NO_PIPELINE") != nullptr;
-    ctx->dbg_pv_no_pipe = getenv("NAE_PV_NO_PIPE") != nullptr;
     ctx->dbg_rs_single = getenv("NAE_RS_SINGLE") != nullptr;
     ctx->dbg_no_mix_fuse = getenv("NAE_NO_MIX_FUSE") != nullptr;
     if (const char* e = getenv("NAE_TD_NC")) ctx->dbg_td_nc = atoi(e);
     ctx->dbg_st_unfused = getenv("NAE_ST_UNFUSED") != nullptr;
-    ctx->dbg_pv_lockstep = 8;
-    if (const char* e = getenv("NAE_PV_LOCKSTEP")) {
-        const int n = atoi(e);
-        ctx->dbg_pv_lockstep = (n > 0 && (n & (n - 1)) == 0) ? n : 0;
-    }
     ctx->dbg_rs_direct = getenv("NAE_RS_DIRECT") != nullptr;
     ctx->dbg_spec_generic = getenv("NAE_SPEC_GENERIC") != nullptr;
-    ctx->dbg_spec_old = getenv("NAE_SPEC_OLD") != nullptr;
     std::vector<nae::cf> w512, t1024;
     std::vector<float> hann;
     build_tables(w512, t1024, hann);

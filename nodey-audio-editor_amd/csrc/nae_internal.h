@@ -27,17 +27,11 @@ struct nae_ctx {
     struct nae_wsola_cache* wsola_cache = nullptr;   // plan + workspaces of nae_wsola_block_f32 (nae_wsola.hip)
     int pv_tile = 0;             // frames per phase-vocoder tile; 0 = choose per call (nae_pick_pv_tile)
     // tuning / A-B switches, read once from the environment at context creation (tools/ab.sh)
-    bool dbg_pv_highocc = false;     // NAE_PV_HIGHOCC: force the 4-waves-per-SIMD synth build (A/B only)
-    bool dbg_pv_lowocc = false;      // NAE_PV_LOWOCC: force the 2-waves-per-SIMD synth build
-    int dbg_pv_lockstep = 8;         // NAE_PV_LOCKSTEP=N: workgroup barrier every N frames in the pipelined synth kernel (0: never)
     bool dbg_st_unfused = false;     // NAE_ST_UNFUSED: WSOLA chain runs filter and cubic stage as separate launches
     int dbg_td_nc = 0;               // NAE_TD_NC=1|2|4: candidates per thread of the WSOLA search (0: by batch size)
-    bool dbg_pv_no_pipe = false;     // NAE_PV_NO_PIPE: round-1 synthesis kernels instead of the three-role wave pipeline
-    bool dbg_pv_no_pipeline = false; // NAE_PV_NO_PIPELINE: use the non-pipelined synth kernel for long tiles
     bool dbg_no_mix_fuse = false;    // NAE_NO_MIX_FUSE: graph4 runs mix and transposer as separate launches
     bool dbg_rs_single = false;      // NAE_RS_SINGLE: one stream per transposer workgroup (no coefficient sharing)
     bool dbg_rs_direct = false;      // NAE_RS_DIRECT: direct (unstaged) transposer kernel
-    bool dbg_spec_old = false;       // NAE_SPEC_OLD: round-1 stereo spectrum kernel (117 VGPRs, 4 waves per SIMD)
     bool dbg_spec_generic = false;   // NAE_SPEC_GENERIC: skip the interleaved-stereo spectrum fast path
     // optional per-kernel timing (hipEvent pairs on the ctx stream), used by bench.py for the roofline line
     bool prof_on = false;

@@ -28,7 +28,6 @@ struct PvParams {
     long long f_origin;   // first frame / output block of tile 0 (0 in block mode; > 0 when a stream is continued)
     long long f_stop;     // one past the last frame / block this launch is responsible for
     int skip_last;        // pass 1 only: the last tile's sum is not needed (nothing is carried on behind it)
-    int lockstep;         // pv_synth2_kernel only: workgroup barrier every `lockstep` frames (power of two; 0 = never)
 };
 
 __device__ __forceinline__ long long frame_start(const PvParams& p, long long f)

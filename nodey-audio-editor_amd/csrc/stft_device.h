@@ -18,7 +18,6 @@ struct cf { float x, y; };
 struct __attribute__((packed, aligned(4))) f2u { float x, y; }; // 8-byte access at 4-byte alignment
 
 constexpr int kScratchCf = 520;                 // per-wave LDS scratch, complex elements (512 for the transposes, 513 natural)
-constexpr int kRingFloats = 4 * NAE_HOP;        // per-wave overlap-add ring: 4 hop blocks
 
 __device__ __forceinline__ void wave_lds_sync()
 {
@@ -126,43 +125,6 @@ __device__ __forceinline__ void fft512_fwd(cf (&v)[8], cf* __restrict__ scratch,
     dft8_fwd(v);
 }
 
-// two independent 512-point FFTs advanced in lockstep (same canonical arithmetic as fft512_fwd on each): the
-// instruction streams interleave, the LDS round trips overlap, and the pair needs 4 wave syncs instead of 8.
-__device__ __forceinline__ void fft512_fwd2(cf (&a)[8], cf (&b)[8], cf* __restrict__ sa, cf* __restrict__ sb, const FftTw& tw,
-                                            int lane)
-{
-    const int m = lane & 7, qq = lane >> 3;
-    dft8_fwd(a);
-    dft8_fwd(b);
-#pragma unroll
-    for (int q = 1; q < 8; q++) { a[q] = cmul_tw(a[q], tw.a[q - 1]); b[q] = cmul_tw(b[q], tw.a[q - 1]); }
-#pragma unroll
-    for (int q = 0; q < 8; q++) { const int o = (lane ^ (q << 3)) + 64 * q; sa[o] = a[q]; sb[o] = b[q]; }
-    wave_lds_sync();
-    {
-        const int base = m + 64 * qq;
-#pragma unroll
-        for (int j = 0; j < 8; j++) { const int o = base + ((j ^ qq) << 3); a[j] = sa[o]; b[j] = sb[o]; }
-    }
-    wave_lds_sync();
-    dft8_fwd(a);
-    dft8_fwd(b);
-#pragma unroll
-    for (int p = 1; p < 8; p++) { const cf w = tw.b[p]; a[p] = cmul_tw(a[p], w); b[p] = cmul_tw(b[p], w); }
-    {
-        const int base = (qq ^ ((m & 3) << 1)) | (m << 6);
-        const int ph = m >> 2;
-#pragma unroll
-        for (int p = 0; p < 8; p++) { const int o = base | ((p ^ ph) << 3); sa[o] = a[p]; sb[o] = b[p]; }
-    }
-    wave_lds_sync();
-#pragma unroll
-    for (int j = 0; j < 8; j++) { const int o = (lane ^ (((j & 3) << 1) | ((j >> 2) << 3))) + 64 * j; a[j] = sa[o]; b[j] = sb[o]; }
-    wave_lds_sync();
-    dft8_fwd(a);
-    dft8_fwd(b);
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // Low-register form of the same FFT (identical arithmetic, so identical bits): every LDS access is a per-lane base
 // register plus an IMMEDIATE offset — no swizzle arithmetic, no hoisted address registers — and the pass-A twiddles
@@ -172,9 +134,11 @@ __device__ __forceinline__ void fft512_fwd2(cf (&a)[8], cf (&b)[8], cf* __restri
 // ds_write_b64 is serviced in 16-lane groups over 32 banks, ds_read_b64 in 32-lane groups over 64 banks
 // (MI355X_MICROARCH.md §LDS): 72 = 8 mod 32 and 66 = 2 mod 16 make each group hit distinct banks.
 // Scratch: 576 complex (4608 B) per wave; natural order [lane + 64 r] (+ one entry at 512) uses the same area.
-// What it buys: ~80 VGPRs instead of 239, i.e. 6 waves per SIMD instead of 2 — and on gfx950 the vector issue rate
-// of a SIMD grows with resident waves up to 8 (profiles/r02_valu_issue.md: one wave alone issues one instruction per
-// 4.5-5 cycles, eight waves together one per 1.0-1.4).
+// What it buys: the FFT alone fits 45 VGPRs (the round-1 form with hoisted swizzle addresses and twiddles in registers
+// needed ~100), so a kernel built on it can keep 6 waves per SIMD resident — and on gfx950 the vector issue rate of a
+// SIMD grows with resident waves up to 8 (profiles/r02_valu_issue.md: one wave alone issues one instruction per 4.5-5
+// cycles, eight waves together one per 1.0-1.4).  Measured alone (profiles/r02_fftpad.md): 141-155 cycles of a CU per
+// FFT at 6-8 waves per SIMD, LDS-bound (16 ds_write_b64 at 3.8 cycles + 30 ds_read_b64 at 1.3 cycles of the CU's LDS pipe).
 constexpr int kPadScratchCf = 576;
 constexpr int kTwaCf = 7 * 64;                   // LDS table W512^(lane q), q = 1..7, laid out [q-1][lane]
 
@@ -284,34 +248,6 @@ __device__ __forceinline__ cf rfft_split(cf (&v)[8], cf* __restrict__ scratch, c
         const cf E = kTwice ? cf{A.x + B.x, A.y - B.y} : cf{h * (A.x + B.x), h * (A.y - B.y)};
         const cf O = kTwice ? cf{A.x - B.x, A.y + B.y} : cf{h * (A.x - B.x), h * (A.y + B.y)};
         const cf P = cmul_tw(O, t1024[k]);
-        v[r] = cf{E.x + P.y, E.y - P.x};
-    }
-    wave_lds_sync();
-    return nyq;
-}
-
-// same split with the lane's 8 split twiddles T1024[lane + 64 r] and T1024[512] already in registers
-__device__ __forceinline__ cf rfft_split_reg(cf (&v)[8], cf* __restrict__ scratch, const cf (&tw)[8], cf tw_nyq, int lane)
-{
-#pragma unroll
-    for (int r = 0; r < 8; r++) scratch[lane + 64 * r] = v[r];
-    wave_lds_sync();
-    cf nyq;
-    {
-        const cf A = scratch[0];
-        const cf E = cf{0.5f * (A.x + A.x), 0.5f * (A.y - A.y)};
-        const cf O = cf{0.5f * (A.x - A.x), 0.5f * (A.y + A.y)};
-        const cf P = cmul_tw(O, tw_nyq);
-        nyq = cf{E.x + P.y, E.y - P.x};
-    }
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-        const int k = lane + 64 * r;
-        const cf A = v[r];
-        const cf B = scratch[(512 - k) & 511];
-        const cf E = cf{0.5f * (A.x + B.x), 0.5f * (A.y - B.y)};
-        const cf O = cf{0.5f * (A.x - B.x), 0.5f * (A.y + B.y)};
-        const cf P = cmul_tw(O, tw[r]);
         v[r] = cf{E.x + P.y, E.y - P.x};
     }
     wave_lds_sync();

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Diagnostic (variant build -DNAE_PIPE_STAMPS, never shipped): per-wave s_memtime stamps around the two barriers of eight
+steps of pv_pipe_kernel, workgroup 0, while the C5 graph runs.  Build: tools/mkvariant.sh stamps -DNAE_PIPE_STAMPS
+Run:   NAE_GPU_LIB=nodey-audio-editor_amd/variants/libnae_gpu_stamps.so python tools/pipe_stamps.py"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import naeload
+
+nae = naeload.load()
+ctx = nae.Context(0)
+n_streams, S, p = 1024, 480000, 2 ** (3 / 12)
+pl = ctx.stretch_plan(1.0, p, S)
+F = ctx.spectrum_frames(pl.out_len)
+d_a, d_b = ctx.empty(n_streams * S * 2), ctx.empty(S * 2)
+ctx.fill_uniform(d_a.ptr, S * 2, S * 2, n_streams, 0, 0)
+ctx.fill_uniform(d_b.ptr, S * 2, 0, 1, 0, 1)
+d_mix, d_pitch, d_spec = ctx.empty(n_streams * S * 2), ctx.empty(n_streams * pl.out_len * 2), ctx.empty(n_streams * F * 2 * 513)
+g = nae.Graph4()
+g.in_a = nae.Sig.interleaved(d_a.ptr, S, 2)
+g.in_b = nae.Sig.interleaved(d_b.ptr, S, 2, shared=True)
+g.vol_a = g.vol_b = 0.5
+g.mix_out = nae.Sig.planar(d_mix.ptr, S, 2)
+g.rate, g.pitch = 1.0, p
+g.pitch_out = nae.Sig.interleaved(d_pitch.ptr, pl.out_len, 2)
+g.spec_out, g.spec_stream_stride = d_spec.ptr, F * 2 * 513
+g.S, g.n_streams = S, n_streams
+for _ in range(3):
+    ctx.graph4(g)
+ctx.sync()
+st = np.zeros(12 * 8 * 4, np.uint64)
+rc = ctx.lib.nae_debug_read_pipe_stamps(st.ctypes.data_as(C.c_void_p))
+assert rc == 0, rc
+st = st.reshape(12, 8, 4).astype(np.int64)
+t0 = st[:, 0, 0].min()
+st -= t0
+names = ["R1"] * 4 + ["R2"] * 4 + ["R3"] * 4
+print("cycles relative to the first stamp; per wave and step: arrive A, leave A, arrive B, leave B")
+for step in range(8):
+    print(f"-- step {200 + step}")
+    for w in range(12):
+        a0, a1, b0, b1 = st[w, step]
+        nxt = st[w, step + 1, 0] if step < 7 else -1
+        print(f"  wave {w:2d} {names[w]} sc{w % 4}: A {a0:7d} -> {a1:7d} (wait {a1 - a0:5d}) | alpha {b0 - a1:5d} | B {b0:7d} -> {b1:7d} (wait {b1 - b0:5d}) | beta {nxt - b1 if nxt >= 0 else -1:5d}")
+per_step = (st[:, 7, 0] - st[:, 0, 0]) / 7.0
+print("cycles per step per wave:", np.round(per_step).astype(int))
+tot = np.zeros(4 * 64, np.uint64)
+assert ctx.lib.nae_debug_read_pipe_total(tot.ctypes.data_as(C.c_void_p)) == 0
+tot = tot.reshape(64, 4)
+cyc, real, steps = tot[:, 0].astype(np.float64), tot[:, 1].astype(np.float64), tot[:, 2].astype(np.float64)
+print("whole loop, R1 wave of 64 sampled workgroups: cycles per step min/median/max =", int((cyc / steps).min()), int(np.median(cyc / steps)), int((cyc / steps).max()),
+      "| clock GHz min/median/max = %.2f %.2f %.2f" % tuple(np.percentile(cyc / real * 0.1, [0, 50, 100])), "| loop ms median = %.3f" % (np.median(real) * 1e-5))
+xcc = (tot[:, 3] >> np.uint64(32)).astype(np.int64) & 0xf
+hw = tot[:, 3].astype(np.int64) & 0xffffffff
+for x in sorted(set(xcc.tolist())):
+    m = xcc == x
+    print(f"xcc {x}: {m.sum():2d} sampled workgroups, cycles/step " + " ".join(str(int(v)) for v in sorted((cyc / steps)[m])) + "  GHz %.2f" % np.median((cyc / real * 0.1)[m]))

@@ -21,7 +21,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct Stamp { unsigned long long cyc, real; unsigned hw_id, xcc_id; };
 
-enum Op { FMA, MUL, ADD, SIN, RCP, SQRT, CVT_I32, MUL_LO_U32, MAD_U64_U32, MAD_I64_I32, AND_B32, CNDMASK, PK_FMA, FMA_DEP, FMA_SIN_9_1, DS_READ_B64, DS_WRITE_B64, DS_READ2_B64, DS_READ2ST64_B64, DS_WRITE2_B64, DS_WRITE2ST64_B64, DS_READ_B128, DS_WRITE_B128, MUL_SGPR, MUL_LIT, CMP_CNDMASK, CNDMASK_S64, MAX_F32, MOV_B32, FMAC_F32, FMAAK_F32, DIV_SCALE, DIV_FMAS, DIV_FIXUP, N_OPS };
+enum Op { FMA, MUL, ADD, SIN, RCP, SQRT, CVT_I32, MUL_LO_U32, MAD_U64_U32, MAD_I64_I32, AND_B32, CNDMASK, PK_FMA, FMA_DEP, FMA_SIN_9_1, DS_READ_B64, DS_WRITE_B64, DS_READ2_B64, DS_READ2ST64_B64, DS_WRITE2_B64, DS_WRITE2ST64_B64, DS_READ_B128, DS_WRITE_B128, MUL_SGPR, MUL_LIT, CMP_CNDMASK, CNDMASK_S64, MAX_F32, MOV_B32, FMAC_F32, FMAAK_F32, DIV_SCALE, DIV_FMAS, DIV_FIXUP, ADD_2SRC, FMA_3SRC, ADD_2SRC_LONG, FMA_3SRC_LONG, FMAC_LONG, MIX_FFT, ADD15_DSW1, ADD15_DSR1, ADD14_DSW1_DSR1, ADD15_GLD1, ADD15_GST1, N_OPS };
 static const char* kOpName[N_OPS] = {"v_fma_f32", "v_mul_f32", "v_add_f32", "v_sin_f32", "v_rcp_f32", "v_sqrt_f32", "v_cvt_i32_f32", "v_mul_lo_u32",
                                      "v_mad_u64_u32", "v_mad_i64_i32", "v_and_b32", "v_cndmask_b32", "v_pk_fma_f32 (2 lanes-ops each)",
                                      "v_fma_f32, ONE dependent chain", "15 v_fma_f32 : 1 v_sin_f32", "ds_read_b64 (no wait inside)", "ds_write_b64 (no wait inside)",
@@ -29,11 +29,16 @@ static const char* kOpName[N_OPS] = {"v_fma_f32", "v_mul_f32", "v_add_f32", "v_s
                                      "ds_write2st64_b64 offset1:1 (16 B/lane)", "ds_read_b128 (16 B/lane)", "ds_write_b128 (16 B/lane)",
                                      "v_mul_f32 with an SGPR operand", "v_mul_f32 with a 32-bit literal", "v_cmp_gt_f32 vcc + v_cndmask_b32 vcc (2 instr)",
                                      "v_cndmask_b32_e64 with an SGPR-pair mask", "v_max_f32", "v_mov_b32", "v_fmac_f32 (VOP2)", "v_fmaak_f32 (literal)",
-                                     "v_div_scale_f32", "v_div_fmas_f32", "v_div_fixup_f32"};
+                                     "v_div_scale_f32", "v_div_fmas_f32", "v_div_fixup_f32",
+                                     "v_add_f32 d, s0, s1: three different VGPRs, rotating", "v_fma_f32 d, s0, s1, s2: four different VGPRs, rotating",
+                                     "same v_add_f32 stream, 4096-instruction loop body (16 KiB of code)", "same v_fma_f32 stream, 4096-instruction loop body (32 KiB)",
+                                     "v_fmac_f32 d += s0*s1 (VOP2), rotating, 4096-instruction body", "add/sub/mul/fma mix of a radix-8 butterfly, rotating registers",
+                                     "15 v_add_f32 : 1 ds_write_b64 (per 16 instructions)", "15 v_add_f32 : 1 ds_read_b64", "14 v_add_f32 : 1 ds_write_b64 : 1 ds_read_b64",
+                                     "15 v_add_f32 : 1 global_load_dwordx2 (L2-resident, 512 B per wave)", "15 v_add_f32 : 1 global_store_dwordx2"};
 
 template <int OP>
 __device__ __forceinline__ void block16(float (&a)[16], float2 (&p)[8], unsigned long long (&w)[8], f32x4 (&q4)[4], float b, float c, unsigned lds_addr,
-                                        unsigned lds_addr16, unsigned long long mask)
+                                        unsigned lds_addr16, unsigned long long mask, float* gptr)
 {
 #pragma unroll
     for (int i = 0; i < 16; i++) {
@@ -74,6 +79,23 @@ __device__ __forceinline__ void block16(float (&a)[16], float2 (&p)[8], unsigned
         if (OP == DIV_SCALE) asm volatile("v_div_scale_f32 %0, vcc, %0, %1, %0" : "+v"(a[i]) : "v"(b) : "vcc");
         if (OP == DIV_FMAS) asm volatile("v_div_fmas_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c) : "vcc");
         if (OP == DIV_FIXUP) asm volatile("v_div_fixup_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+        if (OP == ADD_2SRC || OP == ADD_2SRC_LONG) asm volatile("v_add_f32 %0, %1, %2" : "=v"(a[i]) : "v"(a[(i + 5) & 15]), "v"(a[(i + 10) & 15]));
+        if (OP == FMA_3SRC || OP == FMA_3SRC_LONG) asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(a[i]) : "v"(a[(i + 5) & 15]), "v"(a[(i + 10) & 15]), "v"(a[(i + 13) & 15]));
+        if (OP == FMAC_LONG) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[i]) : "v"(a[(i + 5) & 15]), "v"(a[(i + 10) & 15]));
+        if (OP == MIX_FFT) {
+            if ((i & 3) == 0) asm volatile("v_add_f32 %0, %1, %2" : "=v"(a[i]) : "v"(a[(i + 5) & 15]), "v"(a[(i + 10) & 15]));
+            if ((i & 3) == 1) asm volatile("v_sub_f32 %0, %1, %2" : "=v"(a[i]) : "v"(a[(i + 5) & 15]), "v"(a[(i + 10) & 15]));
+            if ((i & 3) == 2) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(a[i]) : "v"(a[(i + 5) & 15]), "v"(a[(i + 10) & 15]));
+            if ((i & 3) == 3) asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(a[i]) : "v"(a[(i + 5) & 15]), "v"(a[(i + 10) & 15]), "v"(a[(i + 13) & 15]));
+        }
+        if (OP >= ADD15_DSW1 && OP <= ADD15_GST1) {
+            const bool w_slot = (i == 7), r_slot = (OP == ADD14_DSW1_DSR1) ? (i == 15) : (i == 7);
+            if (w_slot && (OP == ADD15_DSW1 || OP == ADD14_DSW1_DSR1)) asm volatile("ds_write_b64 %0, %1" :: "v"(lds_addr), "v"(p[0]));
+            else if (r_slot && (OP == ADD15_DSR1 || OP == ADD14_DSW1_DSR1)) asm volatile("ds_read_b64 %0, %1" : "=v"(p[1]) : "v"(lds_addr));
+            else if (w_slot && OP == ADD15_GLD1) asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(p[2]) : "v"(lds_addr16 & 0x3f8u), "s"(gptr));
+            else if (w_slot && OP == ADD15_GST1) asm volatile("global_store_dwordx2 %0, %1, %2" :: "v"(lds_addr16 & 0x3f8u), "v"(p[3]), "s"(gptr));
+            else asm volatile("v_add_f32 %0, %1, %2" : "=v"(a[i]) : "v"(a[(i + 5) & 15]), "v"(a[(i + 10) & 15]));
+        }
         if (OP == DS_READ_B128) asm volatile("ds_read_b128 %0, %1" : "=v"(q4[i & 3]) : "v"(lds_addr16));
         if (OP == DS_WRITE_B128) asm volatile("ds_write_b128 %0, %1" :: "v"(lds_addr16), "v"(q4[i & 3]));
     }
@@ -95,19 +117,20 @@ __global__ __launch_bounds__(1024) void stream_kernel(Stamp* out, float* sink, i
     for (int i = 0; i < 8; i++) { p[i] = float2{a[i], a[i + 8]}; w[i] = threadIdx.x * 977u + i; }
     const unsigned lds_addr = (unsigned)(size_t)smem + 8u * (threadIdx.x & 63) + 2048u * (threadIdx.x >> 6);    // conflict-free 8-byte slots, 2 KiB per wave
     const unsigned lds_addr16 = (unsigned)(size_t)smem + 16u * (threadIdx.x & 63) + 2048u * (threadIdx.x >> 6);
+    float* gptr = sink + (size_t)(blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * 1024;   // 4 KiB per wave
     const unsigned long long mask = __builtin_amdgcn_readfirstlane(iters) * 0x5555555555555555ull;
     __syncthreads();
     const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+    constexpr bool kLong = (OP == ADD_2SRC_LONG || OP == FMA_3SRC_LONG || OP == FMAC_LONG);
+    const int n_it = kLong ? iters / 64 : iters;        // the long body holds 64 x 64 instructions
 #pragma unroll 1
-    for (int it = 0; it < iters; it++) {
-        block16<OP>(a, p, w, q4, b, c, lds_addr, lds_addr16, mask);
-        block16<OP>(a, p, w, q4, b, c, lds_addr, lds_addr16, mask);
-        block16<OP>(a, p, w, q4, b, c, lds_addr, lds_addr16, mask);
-        block16<OP>(a, p, w, q4, b, c, lds_addr, lds_addr16, mask);
-        if (OP >= DS_READ_B64 && OP <= DS_WRITE_B128) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int it = 0; it < n_it; it++) {
+#pragma unroll
+        for (int u = 0; u < (kLong ? 256 : 4); u++) block16<OP>(a, p, w, q4, b, c, lds_addr, lds_addr16, mask, gptr);
+        if ((OP >= DS_READ_B64 && OP <= DS_WRITE_B128) || OP >= ADD15_DSW1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     const unsigned long long c1 = __builtin_amdgcn_s_memtime();
     const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
     float s = 0.0f;
@@ -153,7 +176,7 @@ int main(int argc, char** argv)
     Stamp* d_out;
     float* d_sink;
     CK(hipMalloc(&d_out, sizeof(Stamp) * n_cu * 2 * 16));
-    CK(hipMalloc(&d_sink, sizeof(float) * n_cu * 2 * 1024));
+    CK(hipMalloc(&d_sink, sizeof(float) * n_cu * 2 * 16 * 1024 + 65536));
     const Cfg cfgs[] = {{1, 256, 1}, {2, 512, 1}, {3, 768, 1}, {4, 1024, 1}, {6, 768, 2}, {8, 1024, 2}};
     printf("# vector-instruction issue interval vs waves per SIMD (tools/ubench/valu_issue.hip)\n\n");
     printf("device: %s (%s), %d CUs; every wave: %d x 64 instructions of one opcode on 16 independent registers between two s_memtime stamps.\n", prop.name,
@@ -172,6 +195,8 @@ int main(int argc, char** argv)
                 CASE(AND_B32) CASE(CNDMASK) CASE(PK_FMA) CASE(FMA_DEP) CASE(FMA_SIN_9_1) CASE(DS_READ_B64) CASE(DS_WRITE_B64) CASE(DS_READ2_B64) CASE(DS_READ2ST64_B64) CASE(DS_WRITE2_B64)
                 CASE(DS_WRITE2ST64_B64) CASE(DS_READ_B128) CASE(DS_WRITE_B128) CASE(MUL_SGPR) CASE(MUL_LIT) CASE(CMP_CNDMASK) CASE(CNDMASK_S64)
                 CASE(MAX_F32) CASE(MOV_B32) CASE(FMAC_F32) CASE(FMAAK_F32) CASE(DIV_SCALE) CASE(DIV_FMAS) CASE(DIV_FIXUP)
+                CASE(ADD_2SRC) CASE(FMA_3SRC) CASE(ADD_2SRC_LONG) CASE(FMA_3SRC_LONG) CASE(FMAC_LONG) CASE(MIX_FFT)
+                CASE(ADD15_DSW1) CASE(ADD15_DSR1) CASE(ADD14_DSW1_DSR1) CASE(ADD15_GLD1) CASE(ADD15_GST1)
 #undef CASE
             }
             std::vector<double> cpi, ghz;
