@@ -26,6 +26,9 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
 SEMITONES = 3.0
 BINS = 513
+# issue interval of an add/sub/mul/fma mix, cycles per wave-instruction per SIMD, by waves resident per SIMD (s_memtime,
+# tools/ubench/valu_issue.hip -> profiles/r02_valu_issue.md, row "add/sub/mul/fma mix of a radix-8 butterfly")
+VALU_MIX_CYCLES_PER_INSTR = {1: 5.44, 2: 2.72, 3: 1.82, 4: 1.94, 6: 1.65, 8: 1.26}
 
 
 def parse():
@@ -137,10 +140,24 @@ def main():
         torch.cuda.synchronize()
     t1 = time.perf_counter()
     elapsed = t1 - t0
+    clock_ghz = ctx.clock_ghz()                            # probe kernel directly behind the timed steps
     kernels = {}
     if not a.no_kernel_timing:
         ctx.prof_enable(False)
         kernels = ctx.prof_report()
+    sustained = None
+    if a.sustain_seconds > 0:
+        # the same step back to back for at least --sustain-seconds (clock and power settled), no per-kernel events
+        n_sus, ts0 = 0, time.perf_counter()
+        while True:
+            for _ in range(20):
+                ctx.graph4(g)
+            ctx.sync()
+            n_sus += 20
+            if time.perf_counter() - ts0 >= a.sustain_seconds:
+                break
+        ts1 = time.perf_counter()
+        sustained = {"seconds": round(ts1 - ts0, 2), "steps": n_sus, "ms_per_step": (ts1 - ts0) / n_sus * 1e3, "clock_GHz_after": round(ctx.clock_ghz(), 3)}
     if dist is not None:
         elapsed = shard.max_over_ranks(dist, elapsed, device=f"cuda:{local_rank}")
         dist.barrier()
@@ -173,28 +190,36 @@ def main():
         gbs = alg_bytes.get(name, 0.0) / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
         kern_report[name] = {"avg_ms": round(avg, 4), "launches": int(cnt), "alg_GBps": round(gbs, 1),
                              "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")    # written from the rocprofv3 --pmc passes
+    # HBM traffic and dynamic instruction counts of each kernel come from rocprofv3 --pmc passes of THIS build over the
+    # same workload (tools/pmc_sq.sh, tools/summarize_prof.py), committed as profiles/traffic.json: counters cannot be
+    # read from inside the run.  Both are scaled by the sample-frames of the launch.
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
     tdata = json.load(open(tpath)) if os.path.exists(tpath) else {}
     if kernels:
         dom = max(kernels, key=lambda k: kernels[k][0])
         avg_s = kernels[dom][0] / max(kernels[dom][1], 1) * 1e-3
         ach = alg_bytes.get(dom, 0.0) / avg_s / 1e9
-        if dom in tdata and tdata[dom].get("sample_frames"):
-            traffic = tdata[dom]["hbm_bytes_per_launch"] * sf / tdata[dom]["sample_frames"]
+        td = tdata.get(dom, {})
+        scale = sf / td["sample_frames"] if td.get("sample_frames") else None
+        traffic = td["hbm_bytes_per_launch"] * scale if scale and "hbm_bytes_per_launch" in td else None
         roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "traffic_source": tdata.get("_source") if traffic is not None else None,
                     "avg_launch_ms": round(avg_s * 1e3, 4), "alg_bytes_per_launch": alg_bytes.get(dom, 0.0),
-                    "note": "K7 is VALU-issue-bound (FFT + atan2/sincos per bin), not HBM-bound; see DESIGN.md §4 and "
-                            "profiles/r01_v6_valu.md (VALUBusy)"}
-        if dom == "pv_synth_kernel" and pl.pv_on:
-            # informational: vector-issue utilisation of the vocoder kernel from its dynamic instruction count (1155 VALU
-            # instructions per wave per frame, rocprofv3 SQ_INSTS_VALU) against the calibrated issue rate of one wave-instruction
-            # per 3.2 cycles per SIMD at 2.4 GHz (tools/ubench/mfma_dft8.hip): 256 CUs x 4 SIMDs x 64 lanes / 3.2 x 2.4 GHz
-            frames = n_streams * 2 * pl.frames
-            roofline["valu_issue_est"] = {"instr_per_frame_wave": 1155, "frames_per_launch": int(frames),
-                                          "achieved_lane_instr_per_s": frames * 1155 * 64 / avg_s, "peak": 49.2e12,
-                                          "frac": round(frames * 1155 * 64 / avg_s / 49.2e12, 3)}
+                    "note": "K7 is bound by vector-instruction issue and LDS traffic (two 512-point FFTs, atan2, sin/cos per bin), not by "
+                            "HBM; see the valu block, DESIGN.md §4 and profiles/"}
+        if scale and "valu_instr_per_launch" in td:
+            # vector-instruction issue: dynamic wave-instructions of the launch (SQ_INSTS_VALU) against the issue interval measured
+            # with s_memtime for an add/sub/mul/fma mix at this kernel's waves per SIMD (profiles/r02_valu_issue.md), at the clock
+            # measured in this run.  1024 SIMDs = 256 CUs x 4.
+            instr = td["valu_instr_per_launch"] * scale
+            ach_cpi = avg_s * clock_ghz * 1e9 * 1024 / instr
+            peak_cpi = VALU_MIX_CYCLES_PER_INSTR[td.get("waves_per_simd", 6)]
+            roofline["valu"] = {"wave_instr_per_launch": instr, "clock_GHz": round(clock_ghz, 3), "waves_per_simd": td.get("waves_per_simd", 6),
+                                "achieved": round(ach_cpi, 3), "peak": peak_cpi, "unit": "cycles per wave-instruction per SIMD (lower is better)",
+                                "frac": round(peak_cpi / ach_cpi, 3),
+                                "lds": {"idx_active_cycles_per_cu": td.get("lds_idx_active_per_cu", None) and td["lds_idx_active_per_cu"] * scale,
+                                        "kernel_cycles": avg_s * clock_ghz * 1e9}}
     chain_gbs = 64.03 * (n_streams * S * a.steps / elapsed) / 1e9   # 24 + 16 + 24.03 B per sample-frame, rank 0's GPU
 
     out = {
@@ -208,7 +233,7 @@ def main():
                    "job_streams": job_streams, "streams_on_rank0": n_streams, "seconds_per_stream": a.seconds, "sample_frames_per_stream": S,
                    "shared_second_input": True, "parallelism": f"streams sharded over {world} GPU(s), no data-path collective",
                    "device": ctx.name()},
-        "roofline": roofline,
+        "roofline": roofline, "clock_GHz": round(clock_ghz, 3), "sustained": sustained,
         "chain": {"alg_bytes_per_sample_frame": 64.03, "alg_GBps_per_gpu": round(chain_gbs, 1),
                   "frac_hbm_peak": round(chain_gbs / HBM_PEAK_GBS, 4)},
         "kernels": kern_report,

@@ -78,6 +78,10 @@ int nae_prof_enable(nae_ctx* ctx, int on);
 int nae_prof_reset(nae_ctx* ctx);
 int nae_prof_get(nae_ctx* ctx, int index, char* name, size_t name_cap, double* total_ms, uint64_t* launches);
 
+/* shader clock (GHz) the GPU holds at this moment, from s_memtime / s_memrealtime stamps of a 1024-workgroup probe kernel
+ * launched on the context's stream: lets a benchmark turn its own kernel times into cycles without assuming a clock. */
+int nae_debug_clock_ghz(nae_ctx* ctx, double* ghz);
+
 /* synthetic input: dst[s*stream_stride + i] = uniform[-1,1) from splitmix64 with
  * seed(s) = 0x9E3779B97F4A7C15*(1 + first_stream + s) + input_index, i < n_per_stream.  Benchmark/test utility. */
 int nae_fill_uniform_f32(nae_ctx* ctx, float* dst, size_t n_per_stream, size_t stream_stride, size_t n_streams,

@@ -11,6 +11,7 @@
 //                    audio-amix.cpp:263-269         K6 to-f32     audio-velocity.cpp:150-232
 //   K3 amix          audio-amix.cpp:293-307         clamp         audio-io.cpp:617-618
 #include "nae_internal.h"
+#include <algorithm>
 
 namespace nae {
 
@@ -500,6 +501,43 @@ int nae_fill_uniform_f32(nae_ctx* ctx, float* dst, size_t n_per_stream, size_t s
         int rc = nae_check(ctx, hipGetLastError(), "fill_uniform_kernel");
         if (rc) return rc;
     }
+    return NAE_OK;
+}
+
+// shader clock the chip holds right now: every wave runs a short dependent FMA chain between two pairs of
+// (s_memtime, s_memrealtime) stamps; clock = delta cycles / delta 100-MHz ticks.  Launched by bench.py directly behind
+// its timed steps (the DVFS state of the load is still in force) so that cycle figures need no assumed GHz.
+__global__ __launch_bounds__(256) void clock_probe_kernel(unsigned long long* __restrict__ out, int iters)
+{
+    float a = 1.0f + 1e-6f * (float)threadIdx.x;
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < iters; i++) a = __builtin_fmaf(a, 1.0000001f, 1e-9f);
+    asm volatile("" : "+v"(a));
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if ((threadIdx.x & 63) == 0 && a != 0.0f) {
+        const size_t w = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        out[2 * w] = c1 - c0;
+        out[2 * w + 1] = r1 - r0;
+    }
+}
+
+int nae_debug_clock_ghz(nae_ctx* ctx, double* ghz)
+{
+    if (!ctx || !ghz) return NAE_ERR_INVALID;
+    const int blocks = 1024, waves = blocks * 4;
+    unsigned long long* d = nullptr;
+    hipError_t e = hipMalloc((void**)&d, sizeof(unsigned long long) * 2 * waves);
+    if (e != hipSuccess) return nae_check(ctx, e, "hipMalloc(clock probe)");
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d, 20000);
+    std::vector<unsigned long long> h(2 * waves);
+    e = hipMemcpyAsync(h.data(), d, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return nae_check(ctx, e, "clock probe");
+    std::vector<double> g(waves);
+    for (int w = 0; w < waves; w++) g[w] = h[2 * w + 1] ? (double)h[2 * w] / (double)h[2 * w + 1] * 0.1 : 0.0;
+    std::nth_element(g.begin(), g.begin() + waves / 2, g.end());
+    *ghz = g[waves / 2];
     return NAE_OK;
 }
 

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(kPipeThreads, 6) void pv_pipe_kernel(SigViewD src, 
         const cf* tsp = t1024 + lane;
         uint32_t qs[9], qp[9];
         {
-            const uint32_t* bp = base_phase + (sc * p.n_tiles + tile) * kT1024Pad;
+            const uint32_t* bp = base_phase + (sc * p.phase_tiles + (long long)tile * p.phase_step) * kT1024Pad;
 #pragma unroll
             for (int r = 0; r < 8; r++) { qs[r] = bp[lane + 64 * r]; qp[r] = 0; }
             qs[8] = bp[512];

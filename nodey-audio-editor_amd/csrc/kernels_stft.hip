@@ -156,7 +156,7 @@ __global__ __launch_bounds__(kThreads, 4) void pv_phase_kernel(SigViewD src, PvP
     if (item >= n_items) return;
     const long long sc = item / p.n_tiles;
     const int tile = (int)(item % p.n_tiles);
-    if (p.skip_last && tile == p.n_tiles - 1) return;   // wave-uniform
+    if (tile >= p.skip_from) return;                    // wave-uniform
     const long long s_idx = sc / p.ch;
     const int c = (int)(sc % p.ch);
     ChanView in{src.base + s_idx * src.ss + c * src.cs, src.fs, p.in_len};
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(kThreads, 4) void pv_phase_kernel(SigViewD src, PvP
 // pass 2: exclusive prefix over tiles, in place.  one thread per (stream-channel, bin).
 // carry_in (optional): phase in front of tile 0, [n_sc][520]; carry_out (optional): phase behind the last tile.
 __global__ void pv_scan_kernel(uint32_t* __restrict__ sums, long long n_sc, int n_tiles,
-                               const uint32_t* __restrict__ carry_in, uint32_t* __restrict__ carry_out, int last_unwritten)
+                               const uint32_t* __restrict__ carry_in, uint32_t* __restrict__ carry_out, int n_read)
 {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long sc = t / kT1024Pad;
@@ -210,7 +210,6 @@ __global__ void pv_scan_kernel(uint32_t* __restrict__ sums, long long n_sc, int 
     if (sc >= n_sc || k >= NAE_FFT_BINS) return;
     uint32_t* p = sums + sc * n_tiles * (long long)kT1024Pad + k;
     uint32_t run = carry_in ? carry_in[sc * kT1024Pad + k] : 0u;
-    const int n_read = last_unwritten ? n_tiles - 1 : n_tiles;   // the last tile's sum may not exist
     int j = 0;
     // the loads do not depend on the running sum: fetch 8 tiles ahead, then prefix them
     for (; j + 8 <= n_read; j += 8) {
@@ -597,7 +596,9 @@ static PvParams make_pv_params(const nae_stretch_plan& pl, size_t in_len, int ch
     const long long cnt = seg ? seg->f_count : (long long)pl.frames;
     p.f_stop = p.f_origin + cnt;
     p.n_tiles = (int)((cnt + tile - 1) / tile);
-    p.skip_last = 0;
+    p.skip_from = p.n_tiles;
+    p.phase_step = 1;
+    p.phase_tiles = p.n_tiles;
     return p;
 }
 
@@ -607,28 +608,39 @@ size_t nae_pv_phase_workspace_bytes(size_t n_frames, int ch, size_t n_streams, i
     return n_streams * ch * n_tiles * kT1024Pad * sizeof(uint32_t);
 }
 
-// pass 1 + 2: leaves the exclusive tile-prefix phases in `phase_ws`.
-// The sum of the LAST tile is only needed when the phase behind it is carried on (a continued stream), so a block
-// call analyses n_tiles-1 tiles here, and nothing at all when the stream-channel is a single tile.
+// pass 1 + 2: leaves the exclusive tile-prefix phases in `phase_ws` (one record per pass-1 tile).
+// Pass 1 may use shorter tiles than pass 3 (`synth_tile` = a multiple of `tile`): its waves are independent, so short
+// tiles keep the chip full on small batches, while pass 3 wants few long tiles (each re-analyses its frames).
+// Only the sums in front of the last synthesis tile are needed, unless the phase behind the segment is carried on (a
+// continued stream): nothing at all when the stream-channel is a single synthesis tile.
 int nae_launch_pv_phase(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig* src, size_t in_len, int ch,
-                        size_t n_streams, int tile, uint32_t* phase_ws, const nae_pv_segment* seg)
+                        size_t n_streams, int tile, int synth_tile, uint32_t* phase_ws, const nae_pv_segment* seg)
 {
+    if (tile <= 0 || synth_tile < tile || synth_tile % tile) return nae_fail(ctx, NAE_ERR_INVALID, "phase tile must divide the synthesis tile");
     PvParams p = make_pv_params(*pl, in_len, ch, tile, seg);
     const long long n_sc = (long long)n_streams * ch;
     if (n_sc * p.n_tiles == 0) return NAE_OK;
     const bool need_last = seg && seg->carry_out;
+    const int step = synth_tile / tile;
+    const int n_synth = (p.n_tiles + step - 1) / step;
+    const int n_needed = need_last ? p.n_tiles : (n_synth - 1) * step;      // sums of tiles [0, n_needed) are used
     Tables tb{ctx->d_w512, ctx->d_t1024, ctx->d_hann};
-    if (p.n_tiles == 1 && !need_last) {
-        // base phase of the only tile: the carried phase, or zero
-        hipError_t e = (seg && seg->carry_in)
-            ? hipMemcpyAsync(phase_ws, seg->carry_in, (size_t)n_sc * kT1024Pad * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream)
-            : hipMemsetAsync(phase_ws, 0, (size_t)n_sc * kT1024Pad * sizeof(uint32_t), ctx->stream);
+    if (n_needed == 0) {
+        // base phase of the only synthesis tile (record 0 of each stream-channel): the carried phase, or zero
+        hipError_t e = hipSuccess;
+        if (!(seg && seg->carry_in))
+            e = hipMemsetAsync(phase_ws, 0, (size_t)n_sc * p.n_tiles * kT1024Pad * sizeof(uint32_t), ctx->stream);
+        else if (p.n_tiles == 1)
+            e = hipMemcpyAsync(phase_ws, seg->carry_in, (size_t)n_sc * kT1024Pad * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream);
+        else
+            e = hipMemcpy2DAsync(phase_ws, (size_t)p.n_tiles * kT1024Pad * sizeof(uint32_t), seg->carry_in, kT1024Pad * sizeof(uint32_t),
+                                 kT1024Pad * sizeof(uint32_t), (size_t)n_sc, hipMemcpyDeviceToDevice, ctx->stream);
         return nae_check(ctx, e, "phase base init");
     }
     {
-        // items are (stream-channel, tile) with tile fastest; the kernel skips tile n_tiles-1 when it is not needed
+        // items are (stream-channel, tile) with tile fastest; the kernel skips the tiles whose sums are not needed
         PvParams pp = p;
-        pp.skip_last = need_last ? 0 : 1;
+        pp.skip_from = n_needed;
         const long long items = n_sc * p.n_tiles;
         const unsigned grid = (unsigned)((items + kWaves - 1) / kWaves);
         const size_t lds = kLdsTables + kWaves * kLdsPerWaveSpec;
@@ -645,16 +657,20 @@ int nae_launch_pv_phase(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig*
         const long long threads = n_sc * kT1024Pad;
         const unsigned grid = (unsigned)((threads + 255) / 256);
         NAE_KLAUNCH(ctx, "pv_scan_kernel", pv_scan_kernel, dim3(grid), dim3(256), 0, ctx->stream, phase_ws, n_sc, p.n_tiles,
-                    seg ? seg->carry_in : nullptr, seg ? seg->carry_out : nullptr, need_last ? 0 : 1);
+                    seg ? seg->carry_in : nullptr, seg ? seg->carry_out : nullptr, n_needed);
         return nae_check(ctx, hipGetLastError(), "pv_scan_kernel");
     }
 }
 
 int nae_launch_pv_synth(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig* src, size_t in_len, int ch,
-                        size_t n_streams, int tile, const uint32_t* phase_ws, const nae_sig* out,
+                        size_t n_streams, int tile, int phase_tile, const uint32_t* phase_ws, const nae_sig* out,
                         const nae_pv_segment* seg)
 {
-    const PvParams p = make_pv_params(*pl, in_len, ch, tile, seg);
+    if (phase_tile <= 0 || tile < phase_tile || tile % phase_tile) return nae_fail(ctx, NAE_ERR_INVALID, "phase tile must divide the synthesis tile");
+    PvParams p = make_pv_params(*pl, in_len, ch, tile, seg);
+    const long long cnt = p.f_stop - p.f_origin;
+    p.phase_step = tile / phase_tile;
+    p.phase_tiles = (int)((cnt + phase_tile - 1) / phase_tile);
     return nae_launch_pv_pipe(ctx, p, to_view(src), (long long)n_streams * ch, phase_ws, to_out(out), src->frame_stride == 1);
 }
 

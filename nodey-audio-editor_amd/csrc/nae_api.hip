@@ -142,19 +142,28 @@ int nae_ensure_rs_table(nae_ctx* ctx, double rate_eff)
     return NAE_OK;
 }
 
-// Tile length of the phase vocoder for a block call.  Every tile costs T+4 analyses for T hops in pass 3 and, unless it
-// is the last tile of its stream-channel, T+1 more in pass 1 — so tiles should be as long as parallelism allows:
-// one tile per stream-channel once those alone fill the chip (measured on C5: 2048 single-tile waves beat 71k
-// 64-frame tiles by 3 ms per step), otherwise just enough tiles for ~16 waves per CU, never shorter than 64 frames.
-int nae_pick_pv_tile(nae_ctx* ctx, size_t frames, size_t n_sc)
+// Tile lengths of the phase vocoder for a block call.  A synthesis tile is one unit of pass 3 (three waves,
+// kernels_pvpipe.hip); four of them make a workgroup and a CU holds two workgroups.  Every synthesis tile but the last of a
+// stream-channel is analysed twice (pass 1 sums its phase increments, pass 3 synthesises it), so synthesis tiles are as
+// long as parallelism allows: none at all once the stream-channels alone give every CU a workgroup (>= 1024 of them),
+// otherwise just enough for two workgroups per CU.  Pass 1 is one wave per tile and wants >= 4096 waves: it runs on tiles
+// `step` times shorter (*phase_tile), never shorter than 64 frames; the synthesis tile is a multiple of it.
+int nae_pick_pv_tile(nae_ctx* ctx, size_t frames, size_t n_sc, int* phase_tile)
 {
-    if (ctx->pv_tile > 0) return ctx->pv_tile;
+    if (ctx->pv_tile > 0) { *phase_tile = ctx->pv_tile; return ctx->pv_tile; }
+    *phase_tile = 64;
     if (frames == 0 || n_sc == 0) return 64;
-    size_t n_tiles = n_sc >= 1536 ? 1 : (4096 + n_sc - 1) / n_sc;
     const size_t max_tiles = (frames + 63) / 64;
-    if (n_tiles > max_tiles) n_tiles = max_tiles;
-    if (n_tiles < 1) n_tiles = 1;
-    return (int)((frames + n_tiles - 1) / n_tiles);
+    size_t n_synth = n_sc >= 1024 ? 1 : (2048 + n_sc - 1) / n_sc;
+    if (n_synth > max_tiles) n_synth = max_tiles;
+    size_t n_phase = n_synth == 1 ? 1 : (4096 + n_sc - 1) / n_sc;      // a single synthesis tile needs no pass 1
+    if (n_phase > max_tiles) n_phase = max_tiles;
+    size_t step = (n_phase + n_synth - 1) / n_synth;
+    if (step < 1) step = 1;
+    size_t pt = (frames + n_synth * step - 1) / (n_synth * step);
+    if (pt < 64) pt = 64;
+    *phase_tile = (int)pt;
+    return (int)(pt * step);
 }
 
 extern "C" {
@@ -461,13 +470,14 @@ static int stretch_block_impl(nae_ctx* ctx, double rate, double pitch, const nae
     }
     if ((rc = run_mix())) return rc;     // vocoder first / transposer only: the mix is a launch of its own
     if (pl.pv_on) {
-        const int tile = nae_pick_pv_tile(ctx, pl.frames, n_streams * ch);
-        rc = nae_ws_reserve(ctx, &ctx->ws_phase, &ctx->ws_phase_bytes, nae_pv_phase_workspace_bytes(pl.frames, ch, n_streams, tile));
+        int phase_tile = 0;
+        const int tile = nae_pick_pv_tile(ctx, pl.frames, n_streams * ch, &phase_tile);
+        rc = nae_ws_reserve(ctx, &ctx->ws_phase, &ctx->ws_phase_bytes, nae_pv_phase_workspace_bytes(pl.frames, ch, n_streams, phase_tile));
         if (rc) return rc;
         nae_pv_segment seg{0, (long long)pl.frames, (long long)pl.frames, pv_out_len, nullptr, nullptr};
-        rc = nae_launch_pv_phase(ctx, &pl, pv_src, pv_in_len, ch, n_streams, tile, static_cast<uint32_t*>(ctx->ws_phase), &seg);
+        rc = nae_launch_pv_phase(ctx, &pl, pv_src, pv_in_len, ch, n_streams, phase_tile, tile, static_cast<uint32_t*>(ctx->ws_phase), &seg);
         if (rc) return rc;
-        rc = nae_launch_pv_synth(ctx, &pl, pv_src, pv_in_len, ch, n_streams, tile, static_cast<const uint32_t*>(ctx->ws_phase), pv_dst, &seg);
+        rc = nae_launch_pv_synth(ctx, &pl, pv_src, pv_in_len, ch, n_streams, tile, phase_tile, static_cast<const uint32_t*>(ctx->ws_phase), pv_dst, &seg);
         if (rc) return rc;
     }
     if (pl.rs_on && !pl.rs_first) {
@@ -523,7 +533,7 @@ int nae_debug_pv_tile_phase(nae_ctx* ctx, double rate, double pitch, const nae_s
         pv_in_len = pl.mid_len;
     }
     nae_pv_segment seg{0, (long long)pl.frames, (long long)pl.frames, 0, nullptr, nullptr};
-    rc = nae_launch_pv_phase(ctx, &pl, pv_src, pv_in_len, ch, n_streams, tile, static_cast<uint32_t*>(ctx->ws_phase), &seg);
+    rc = nae_launch_pv_phase(ctx, &pl, pv_src, pv_in_len, ch, n_streams, tile, tile, static_cast<uint32_t*>(ctx->ws_phase), &seg);
     if (rc) return rc;
     std::vector<int32_t> tmp(ws_bytes / sizeof(int32_t));
     hipError_t e = hipMemcpyAsync(tmp.data(), ctx->ws_phase, ws_bytes, hipMemcpyDeviceToHost, ctx->stream);

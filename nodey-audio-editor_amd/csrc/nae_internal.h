@@ -73,16 +73,16 @@ struct nae_pv_segment {
 };
 size_t nae_pv_phase_workspace_bytes(size_t n_frames, int ch, size_t n_streams, int tile);
 int nae_launch_pv_phase(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig* src, size_t in_len, int ch,
-                        size_t n_streams, int tile, uint32_t* phase_ws, const nae_pv_segment* seg);
+                        size_t n_streams, int tile, int synth_tile, uint32_t* phase_ws, const nae_pv_segment* seg);
 int nae_launch_pv_synth(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig* src, size_t in_len, int ch,
-                        size_t n_streams, int tile, const uint32_t* phase_ws, const nae_sig* out,
+                        size_t n_streams, int tile, int phase_tile, const uint32_t* phase_ws, const nae_sig* out,
                         const nae_pv_segment* seg);
 int nae_launch_resample(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig* src, size_t src_len, int ch,
                         size_t n_streams, const float* d_tab, const nae_sig* out, size_t j_begin, size_t j_end);
 int nae_launch_mix_resample(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig* a, const nae_sig* b, float va, float vb,
                             const nae_sig* mix_out, size_t S, size_t n_streams, const float* d_tab, const nae_sig* out);
 int nae_ensure_rs_table(nae_ctx* ctx, double rate_eff);
-int nae_pick_pv_tile(nae_ctx* ctx, size_t frames, size_t n_sc);
+int nae_pick_pv_tile(nae_ctx* ctx, size_t frames, size_t n_sc, int* phase_tile);
 constexpr int kPhasePad = 520; // int32 per (stream-channel, tile) record in the phase workspace
 
 // nae_wsola.hip

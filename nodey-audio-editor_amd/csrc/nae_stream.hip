@@ -203,9 +203,9 @@ int stretch_process(nae_stretch* h)
             if (rc) return rc;
             nae_sig src{h->mid.cur.p - (ptrdiff_t)h->mid.base * ch, 0, 1, (size_t)ch};
             nae_sig dst{h->out.cur.p - (ptrdiff_t)h->out.base * ch, 0, 1, (size_t)ch};
-            rc = nae_launch_pv_phase(ctx, &pl, &src, h->mid_total, ch, 1, tile, static_cast<uint32_t*>(ctx->ws_phase), &seg);
+            rc = nae_launch_pv_phase(ctx, &pl, &src, h->mid_total, ch, 1, tile, tile, static_cast<uint32_t*>(ctx->ws_phase), &seg);
             if (rc) return rc;
-            rc = nae_launch_pv_synth(ctx, &pl, &src, h->mid_total, ch, 1, tile, static_cast<const uint32_t*>(ctx->ws_phase), &dst, &seg);
+            rc = nae_launch_pv_synth(ctx, &pl, &src, h->mid_total, ch, 1, tile, tile, static_cast<const uint32_t*>(ctx->ws_phase), &dst, &seg);
             if (rc) return rc;
             h->carry_cur ^= 1;
             h->blocks_done = B_r;
@@ -269,9 +269,9 @@ int stretch_process(nae_stretch* h)
                 dst = nae_sig{h->out.cur.p - (ptrdiff_t)h->out.base * ch, 0, 1, (size_t)ch};
                 if (h->flushed) seg.mid_limit = (long long)fin.out_len;
             }
-            rc = nae_launch_pv_phase(ctx, &pl, &src, h->in_total, ch, 1, tile, static_cast<uint32_t*>(ctx->ws_phase), &seg);
+            rc = nae_launch_pv_phase(ctx, &pl, &src, h->in_total, ch, 1, tile, tile, static_cast<uint32_t*>(ctx->ws_phase), &seg);
             if (rc) return rc;
-            rc = nae_launch_pv_synth(ctx, &pl, &src, h->in_total, ch, 1, tile, static_cast<const uint32_t*>(ctx->ws_phase), &dst, &seg);
+            rc = nae_launch_pv_synth(ctx, &pl, &src, h->in_total, ch, 1, tile, tile, static_cast<const uint32_t*>(ctx->ws_phase), &dst, &seg);
             if (rc) return rc;
             h->carry_cur ^= 1;
             h->blocks_done = B_r;

@@ -27,7 +27,9 @@ struct PvParams {
     int n_tiles;
     long long f_origin;   // first frame / output block of tile 0 (0 in block mode; > 0 when a stream is continued)
     long long f_stop;     // one past the last frame / block this launch is responsible for
-    int skip_last;        // pass 1 only: the last tile's sum is not needed (nothing is carried on behind it)
+    int skip_from;        // pass 1 only: tiles >= skip_from are not analysed (their sums are not needed)
+    int phase_step;       // pass 3 only: pass 1 ran on tiles `phase_step` times shorter (more waves for the same frames);
+    int phase_tiles;      //              the base phase of tile t is record t * phase_step of `phase_tiles` per stream-channel
 };
 
 __device__ __forceinline__ long long frame_start(const PvParams& p, long long f)

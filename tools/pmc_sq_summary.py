@@ -1,16 +1,29 @@
 #!/usr/bin/env python3
-"""Summarise the rocprofv3 --pmc passes of tools/pmc_sq.sh: per kernel, the median over dispatches of every counter
-(summed over the chip by rocprofv3), plus the ratios that say what a kernel waits for.
+"""Turn the rocprofv3 output of tools/pmc_sq.sh into the committed summaries:
 
-  python tools/pmc_sq_summary.py gpurun_out/<dir> > profiles/rNN_sq_stalls.md
+  python tools/pmc_sq_summary.py gpurun_out/<dir> <tag> [sample_frames_per_launch]
 
-Units (MI355X_MICROARCH.md): SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* / SQ_BUSY_CYCLES count quad-cycles."""
+writes profiles/<tag>_kernel_stats.csv (verbatim --kernel-trace --stats), profiles/<tag>_sq_stalls.md (issue / stall / LDS
+counters per kernel), profiles/<tag>_pmc.md (HBM bytes per launch) and profiles/traffic.json (what bench.py reads for
+`roofline.traffic` and `roofline.valu`).
+
+Units (MI355X_MICROARCH.md): SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* / SQ_BUSY_CYCLES count quad-cycles; FETCH_SIZE and
+WRITE_SIZE are KiB.  gfx950 correction (§HBM): FETCH_SIZE tallies the 128-B requests of a wide coalesced read as 64 B, i.e.
+reports half the bytes -> doubled here (calibrated in round 1 on the mix kernel, whose compulsory read is known); WRITE_SIZE is
+exact for 16-byte-per-lane streaming stores."""
 import collections
 import csv
 import glob
+import json
 import os
 import re
+import shutil
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# kernel symbol -> the launch label bench.py reports it under
+LABEL = {"pv_pipe_kernel": "pv_synth_kernel", "spectrum_stereo_kernel": "spectrum_kernel"}
+WAVES_PER_SIMD = {"pv_pipe_kernel": 6, "spectrum_stereo_kernel": 4, "mix_resample_tile_kernel": 5}
 
 
 def norm(name):
@@ -19,38 +32,66 @@ def norm(name):
 
 
 def main():
-    d = sys.argv[1]
+    d, tag = sys.argv[1], sys.argv[2]
+    sf = int(sys.argv[3]) if len(sys.argv) > 3 else 1024 * 480000
+    prof = os.path.join(ROOT, "profiles")
     vals = collections.defaultdict(lambda: collections.defaultdict(list))
-    for path in sorted(glob.glob(os.path.join(d, "p*", "**", "*counter_collection.csv"), recursive=True)):
+    meta = {}
+    for path in sorted(glob.glob(os.path.join(d, "p[1-9]*", "**", "*counter_collection.csv"), recursive=True)):
         per_dispatch = collections.defaultdict(float)
         kname = {}
         for r in csv.DictReader(open(path)):
-            key = (r["Dispatch_Id"], r["Counter_Name"])
-            per_dispatch[key] += float(r["Counter_Value"])
-            kname[r["Dispatch_Id"]] = norm(r["Kernel_Name"])
+            per_dispatch[(r["Dispatch_Id"], r["Counter_Name"])] += float(r["Counter_Value"])
+            k = norm(r["Kernel_Name"])
+            kname[r["Dispatch_Id"]] = k
+            g = lambda *names: next((r[n] for n in names if n in r), "0")
+            meta[k] = {"vgpr": int(g("VGPR_Count", "Vgpr_Count")), "lds": int(g("LDS_Block_Size", "Lds_Block_Size")), "wg": int(g("Workgroup_Size"))}
         for (disp, cname), v in per_dispatch.items():
             vals[kname[disp]][cname].append(v)
     med = {k: {c: sorted(v)[len(v) // 2] for c, v in cs.items()} for k, cs in vals.items()}
-    keep = [k for k in med if not k.startswith("__amd") and "fill_uniform" not in k]
+    keep = [k for k in med if not k.startswith("__amd") and "fill_uniform" not in k and "clock_probe" not in k]
     keep.sort(key=lambda k: -med[k].get("SQ_WAVE_CYCLES", 0))
-    print("# SQ issue / stall counters per kernel (median over dispatches; rocprofv3 --pmc, one pass per group: tools/pmc_sq.sh)\n")
-    counters = sorted({c for k in keep for c in med[k]})
-    print("| counter | " + " | ".join(keep) + " |")
-    print("|---|" + "---|" * len(keep))
-    for c in counters:
-        print(f"| {c} | " + " | ".join(f"{med[k].get(c, float('nan')):.4g}" for k in keep) + " |")
-    print("\nDerived (per kernel):\n")
-    print("| kernel | wait_any / wave_cycles | wait_inst_any / wave_cycles | active_inst_any / wave_cycles | active_valu / wave_cycles | active_lds / wave_cycles | "
-          "VALU instr | trans share | int32+int64 share | LDS instr | bank-conflict / idx_active | waves |")
-    print("|---|---|---|---|---|---|---|---|---|---|---|---|")
+
+    dur = {}
+    for path in glob.glob(os.path.join(d, "p0", "**", "*kernel_stats.csv"), recursive=True):
+        shutil.copy(path, os.path.join(prof, f"{tag}_kernel_stats.csv"))
+        for r in csv.DictReader(open(path)):
+            avg = r.get("AverageNs") or r.get("Average (Nsec)")
+            dur[norm(r["Name"])] = float(avg) / 1e6
+
+    out = [f"# {tag}: SQ issue / stall / LDS counters per kernel (median over dispatches; rocprofv3 --pmc, one pass per group: tools/pmc_sq.sh)", "",
+           "| counter | " + " | ".join(keep) + " |", "|---|" + "---|" * len(keep)]
+    for c in sorted({c for k in keep for c in med[k]}):
+        out.append(f"| {c} | " + " | ".join(f"{med[k].get(c, float('nan')):.4g}" for k in keep) + " |")
+    out += ["", "Derived (per kernel; avg ms from the --kernel-trace --stats pass):", "",
+            "| kernel | avg ms | VGPR | waves | wait_any / wave_cycles | wait_inst_any / wave_cycles | active_valu / wave_cycles | VALU instr | trans share | int share | LDS instr | "
+            "LDS idx-active cycles per CU | bank-conflict share |", "|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
     for k in keep:
-        m = med[k]
-        g = lambda c: m.get(c, float("nan"))
+        g = lambda c: med[k].get(c, float("nan"))
         wc = g("SQ_WAVE_CYCLES")
-        print(f"| {k} | {g('SQ_WAIT_ANY') / wc:.3f} | {g('SQ_WAIT_INST_ANY') / wc:.3f} | {g('SQ_ACTIVE_INST_ANY') / wc:.3f} | {g('SQ_ACTIVE_INST_VALU') / wc:.3f} | "
-              f"{g('SQ_ACTIVE_INST_LDS') / wc:.3f} | {g('SQ_INSTS_VALU'):.4g} | {g('SQ_INSTS_VALU_TRANS_F32') / g('SQ_INSTS_VALU'):.3f} | "
-              f"{(g('SQ_INSTS_VALU_INT32') + g('SQ_INSTS_VALU_INT64')) / g('SQ_INSTS_VALU'):.3f} | {g('SQ_INSTS_LDS'):.4g} | "
-              f"{g('SQ_LDS_BANK_CONFLICT') / g('SQ_LDS_IDX_ACTIVE'):.3f} | {g('SQ_WAVES'):.4g} |")
+        out.append(f"| {k} | {dur.get(k, float('nan')):.3f} | {meta[k]['vgpr']} | {g('SQ_WAVES'):.4g} | {g('SQ_WAIT_ANY') / wc:.3f} | {g('SQ_WAIT_INST_ANY') / wc:.3f} | "
+                   f"{g('SQ_ACTIVE_INST_VALU') / wc:.3f} | {g('SQ_INSTS_VALU'):.4g} | {g('SQ_INSTS_VALU_TRANS_F32') / g('SQ_INSTS_VALU'):.3f} | "
+                   f"{(g('SQ_INSTS_VALU_INT32') + g('SQ_INSTS_VALU_INT64')) / g('SQ_INSTS_VALU'):.3f} | {g('SQ_INSTS_LDS'):.4g} | {g('SQ_LDS_IDX_ACTIVE') / 256:.4g} | "
+                   f"{g('SQ_LDS_BANK_CONFLICT') / g('SQ_LDS_IDX_ACTIVE'):.3f} |")
+    open(os.path.join(prof, f"{tag}_sq_stalls.md"), "w").write("\n".join(out) + "\n")
+
+    traffic = {"_source": f"profiles/{tag}_pmc.md, profiles/{tag}_sq_stalls.md (rocprofv3 --pmc passes of this build, tools/pmc_sq.sh)"}
+    lines = [f"# {tag}: HBM traffic per launch from rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes)", "", f"sample-frames per launch: {sf}", "",
+             "| kernel | avg ms (--kernel-trace --stats) | FETCH_SIZE KiB (raw) | read bytes (x2 gfx950 corr.) | WRITE_SIZE KiB | HBM bytes/launch | B per sample-frame | VGPR | LDS B/WG |",
+             "|---|---|---|---|---|---|---|---|---|"]
+    for k in keep:
+        if "FETCH_SIZE" not in med[k]:
+            continue
+        rd, wr = med[k]["FETCH_SIZE"] * 1024 * 2, med[k].get("WRITE_SIZE", 0) * 1024
+        traffic[LABEL.get(k, k)] = {"kernel": k, "hbm_bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr, "sample_frames": sf,
+                                    "valu_instr_per_launch": med[k].get("SQ_INSTS_VALU"), "lds_idx_active_per_cu": med[k].get("SQ_LDS_IDX_ACTIVE", 0) / 256,
+                                    "waves_per_simd": WAVES_PER_SIMD.get(k, 4)}
+        lines.append(f"| {k} | {dur.get(k, float('nan')):.3f} | {med[k]['FETCH_SIZE']:.0f} | {rd:.4g} | {med[k].get('WRITE_SIZE', 0):.0f} | {rd + wr:.4g} | {(rd + wr) / sf:.2f} | "
+                     f"{meta[k]['vgpr']} | {meta[k]['lds']} |")
+    open(os.path.join(prof, f"{tag}_pmc.md"), "w").write("\n".join(lines) + "\n")
+    json.dump(traffic, open(os.path.join(prof, "traffic.json"), "w"), indent=1)
+    print("\n".join(out[-len(keep) - 3:]))
+    print("\n".join(lines))
 
 
 if __name__ == "__main__":
