@@ -82,6 +82,10 @@ int nae_prof_get(nae_ctx* ctx, int index, char* name, size_t name_cap, double* t
  * launched on the context's stream: lets a benchmark turn its own kernel times into cycles without assuming a clock. */
 int nae_debug_clock_ghz(nae_ctx* ctx, double* ghz);
 
+/* test utility: adds the number of differing 32-bit words of two device buffers to the device counter *d_count (zero it
+ * first with nae_memset); asynchronous on the context's stream. */
+int nae_debug_diff_u32(nae_ctx* ctx, const void* a, const void* b, size_t n_words, uint64_t* d_count);
+
 /* synthetic input: dst[s*stream_stride + i] = uniform[-1,1) from splitmix64 with
  * seed(s) = 0x9E3779B97F4A7C15*(1 + first_stream + s) + input_index, i < n_per_stream.  Benchmark/test utility. */
 int nae_fill_uniform_f32(nae_ctx* ctx, float* dst, size_t n_per_stream, size_t stream_stride, size_t n_streams,

@@ -19,7 +19,7 @@ EXPORTED_SYMBOLS = [
     "nae_ctx_stream", "nae_sync", "nae_poll", "nae_last_error", "nae_device_name", "nae_malloc", "nae_free",
     "nae_memcpy_h2d", "nae_memcpy_d2h", "nae_memcpy_d2d", "nae_memset", "nae_event_create", "nae_event_record",
     "nae_event_elapsed_ms", "nae_event_destroy", "nae_prof_enable", "nae_prof_reset", "nae_prof_get",
-    "nae_debug_clock_ghz", "nae_fill_uniform_f32", "nae_gain_f32", "nae_gain_s16", "nae_gain_s32", "nae_gain_frame",
+    "nae_debug_clock_ghz", "nae_debug_diff_u32", "nae_fill_uniform_f32", "nae_gain_f32", "nae_gain_s16", "nae_gain_s32", "nae_gain_frame",
     "nae_deinterleave_f32", "nae_interleave_f32", "nae_copy_sig_f32", "nae_gain_sig_f32", "nae_amix_f32",
     "nae_amix_sig_f32", "nae_bimix_f32", "nae_bimix2_downmix_f32", "nae_bimix2_interleave_f32",
     "nae_to_f32_interleaved", "nae_clamp_f32", "nae_stretch_plan_make", "nae_stretch_block_f32",
@@ -117,6 +117,7 @@ def load_library() -> C.CDLL:
         "nae_prof_enable": (i, [vp, i]), "nae_prof_reset": (i, [vp]),
         "nae_prof_get": (i, [vp, i, C.c_char_p, sz, P(d), P(C.c_uint64)]),
         "nae_debug_clock_ghz": (i, [vp, P(C.c_double)]),
+        "nae_debug_diff_u32": (i, [vp, vp, vp, sz, vp]),
         "nae_fill_uniform_f32": (i, [vp, vp, sz, sz, sz, C.c_uint64, C.c_uint64]),
         "nae_gain_f32": (i, [vp, P(vp), P(vp), i, sz, f]), "nae_gain_s16": (i, [vp, P(vp), P(vp), i, sz, f]),
         "nae_gain_s32": (i, [vp, P(vp), P(vp), i, sz, f]),
@@ -293,6 +294,10 @@ class Context:
             self.lib.nae_prof_get(self.h, k, name, 128, C.byref(ms), C.byref(cnt))
             out[name.value.decode()] = (ms.value, cnt.value)
         return out
+
+    def diff_words(self, a: int, b: int, n_words: int, d_count: int) -> None:
+        """adds the number of differing 32-bit words of device buffers a, b to the device uint64 at d_count (asynchronous)"""
+        self._ck(self.lib.nae_debug_diff_u32(self.h, a, b, n_words, d_count))
 
     def clock_ghz(self) -> float:
         """shader clock the GPU holds right now (probe kernel on the context's stream)"""

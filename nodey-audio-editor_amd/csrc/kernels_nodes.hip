@@ -504,6 +504,28 @@ int nae_fill_uniform_f32(nae_ctx* ctx, float* dst, size_t n_per_stream, size_t s
     return NAE_OK;
 }
 
+// test utility: number of 32-bit words that differ between two device buffers, added to *d_count (full-size parity tests
+// compare whole outputs on the device instead of copying gigabytes to the host)
+__global__ __launch_bounds__(256) void diff_u32_kernel(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, size_t n,
+                                                      unsigned long long* __restrict__ d_count)
+{
+    unsigned long long local = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) local += a[i] != b[i];
+    for (int off = 32; off; off >>= 1) local += __shfl_down(local, off);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(d_count, local);
+}
+
+int nae_debug_diff_u32(nae_ctx* ctx, const void* a, const void* b, size_t n_words, uint64_t* d_count)
+{
+    if (!ctx || !d_count || (n_words && (!a || !b))) return NAE_ERR_INVALID;
+    if (n_words == 0) return NAE_OK;
+    size_t blocks = (n_words + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(diff_u32_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, static_cast<const uint32_t*>(a),
+                       static_cast<const uint32_t*>(b), n_words, reinterpret_cast<unsigned long long*>(d_count));
+    return nae_check(ctx, hipGetLastError(), "diff_u32_kernel");
+}
+
 // shader clock the chip holds right now: every wave runs a short dependent FMA chain between two pairs of
 // (s_memtime, s_memrealtime) stamps; clock = delta cycles / delta 100-MHz ticks.  Launched by bench.py directly behind
 // its timed steps (the DVFS state of the load is still in force) so that cycle figures need no assumed GHz.

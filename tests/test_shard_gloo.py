@@ -1,5 +1,6 @@
-"""CPU, world_size 2, gloo: the N>1 path of bench.py — stream sharding, the one-shot broadcast of the shared source
-buffer, and the max-over-ranks timing — exercised without a GPU."""
+"""CPU, world_size 2, gloo: the N>1 path of bench.py — strong-scaling stream sharding (a fixed job cut into contiguous
+slices, BASELINE.json configs[4]), the one-shot broadcast of the shared source buffer, and the max-over-ranks timing —
+exercised without a GPU."""
 import os
 import socket
 import sys
@@ -18,7 +19,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, per_rank, n, q):
+def _worker(rank, world, port, total, n, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -29,7 +30,7 @@ def _worker(rank, world, port, per_rank, n, q):
     nae = naeload.load()
     from nodey_audio_editor_amd import shard
     dist = shard.init("gloo", rank, world)
-    first, last = shard.stream_range(rank, per_rank)
+    first, last = shard.strong_range(rank, world, total)
     # every rank generates ITS streams; rank 0 also generates the shared second input and broadcasts it
     mine = [orc.fill_uniform(n, shard.stream_seed(s, 0)) for s in range(first, last)]
     shared = torch.zeros(n, dtype=torch.float32)
@@ -46,11 +47,11 @@ def test_two_rank_sharding_and_broadcast():
     import torch.multiprocessing as mp
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orc
-    world, per_rank, n = 2, 3, 4096
+    world, total, n = 2, 5, 4096                           # 5 streams over 2 ranks: slices of 2 and 3
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, per_rank, n, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, n, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in range(world)])
@@ -60,13 +61,13 @@ def test_two_rank_sharding_and_broadcast():
     ref_shared = orc.fill_uniform(n, (0x9E3779B97F4A7C15 * 1 + 1) & 0xFFFFFFFFFFFFFFFF)
     covered = []
     for rank, first, last, firsts, shared, elapsed in res:
-        assert (first, last) == (rank * per_rank, (rank + 1) * per_rank)
+        assert (first, last) == (rank * total // world, (rank + 1) * total // world)
         covered += list(range(first, last))
         assert np.array_equal(shared, ref_shared)               # broadcast delivered rank 0's buffer
         assert abs(elapsed - 0.020) < 1e-9                      # max over ranks
         for i, s in enumerate(range(first, last)):
             assert firsts[i] == float(orc.fill_uniform(1, (0x9E3779B97F4A7C15 * (1 + s)) & 0xFFFFFFFFFFFFFFFF)[0])
-    assert covered == list(range(world * per_rank))             # disjoint and complete
+    assert covered == list(range(total))                        # disjoint and complete
 
 
 def test_job_throughput_is_whole_job(nae):
@@ -74,3 +75,11 @@ def test_job_throughput_is_whole_job(nae):
     assert shard.job_throughput(8, 1024, 480000, 5, 0.25) == 8 * 1024 * 480000 * 5 / 0.25
     assert shard.stream_seed(0, 1) == (0x9E3779B97F4A7C15 + 1) & 0xFFFFFFFFFFFFFFFF
     assert shard.stream_range(3, 128) == (384, 512)
+    # strong scaling: 1024 streams over 8 ranks = 128 each; uneven jobs differ by at most one stream and cover the job
+    assert [shard.strong_range(r, 8, 1024) for r in (0, 7)] == [(0, 128), (896, 1024)]
+    for total, world in ((1024, 8), (1000, 8), (5, 2), (3, 4)):
+        cuts = [shard.strong_range(r, world, total) for r in range(world)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == total and all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
+        sizes = [b - a for a, b in cuts]
+        assert max(sizes) - min(sizes) <= 1
+    assert shard.job_throughput_total(1024, 480000, 5, 0.25) == 1024 * 480000 * 5 / 0.25
