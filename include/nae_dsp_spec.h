@@ -46,6 +46,16 @@
 #define NAE_RATE_MIN (1.0 / 16.0)
 #define NAE_RATE_MAX 16.0
 
+/* N2 input resampler: libswresample's defaults when only rates / formats / layouts are set (SURVEY.md Appendix B;
+ * /root/reference/src/processor/audio-amix.cpp:217-232 never touches the resampler options): polyphase
+ * Kaiser-windowed sinc, filter_size 32, phase_shift 10 (1024 phases, nearest phase, no interpolation between phases),
+ * kaiser_beta 9, cutoff 0.97.  Restated from public knowledge of FFmpeg 7.1's resample.c — UNPINNED versus FFmpeg. */
+#define NAE_SWR_FILTER_SIZE 32
+#define NAE_SWR_PHASE_SHIFT 10
+#define NAE_SWR_KAISER_BETA 9.0
+#define NAE_SWR_CUTOFF 0.97
+#define NAE_SWR_MAX_TAPS 512    /* filter_length = ceil(32 / factor): down-conversion by up to ~15x */
+
 /* x86 "integer indefinite" produced by cvttss2si on overflow/NaN: what the reference's
  * truncating float->int32 gain path yields out of range (audio-vol.cpp:98, int32_t case). */
 #define NAE_X86_INT_INDEFINITE (-2147483647 - 1)

@@ -9,48 +9,7 @@
 #include <string.h>
 #include <utility>
 
-namespace {
-
-struct DevBuf {
-    float* p = nullptr;
-    size_t cap = 0; // floats
-    size_t len = 0; // floats in use
-};
-
-int devbuf_reserve(nae_ctx* ctx, DevBuf& b, size_t want)
-{
-    if (want <= b.cap) return NAE_OK;
-    size_t cap = b.cap ? b.cap : 1 << 16;
-    while (cap < want) cap *= 2;
-    float* np = nullptr;
-    if (hipMalloc((void**)&np, cap * sizeof(float)) != hipSuccess) return nae_fail(ctx, NAE_ERR_NOMEM, "hipMalloc(stream buffer)");
-    if (b.len) {
-        hipError_t e = hipMemcpyAsync(np, b.p, b.len * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream);
-        if (e != hipSuccess) { (void)hipFree(np); return nae_check(ctx, e, "hipMemcpyAsync(grow)"); }
-    }
-    if (b.p) {
-        (void)hipStreamSynchronize(ctx->stream);
-        (void)hipFree(b.p);
-    }
-    b.p = np;
-    b.cap = cap;
-    return NAE_OK;
-}
-
-void devbuf_free(DevBuf& b)
-{
-    if (b.p) (void)hipFree(b.p);
-    b = DevBuf{};
-}
-
-} // namespace
-
-// A FIFO of device samples addressed by ABSOLUTE index: element i (i >= base) lives at cur.p[(i - base) * width + ...].
-// Dropping the consumed head copies the tail into the alternate buffer (regions may overlap, so never in place).
-struct DevFifo {
-    DevBuf cur, alt;
-    size_t base = 0;   // absolute index of cur.p[0]
-};
+#include "stream_util.h"
 
 struct nae_stretch {
     nae_ctx* ctx;
@@ -83,33 +42,6 @@ struct nae_spectrum {
 };
 
 namespace {
-
-void fifo_free(DevFifo& f) { devbuf_free(f.cur); devbuf_free(f.alt); }
-
-// keep elements [new_base, total) of an interleaved FIFO (width floats per element)
-int fifo_drop_interleaved(nae_ctx* ctx, DevFifo& f, size_t new_base, size_t total, size_t width)
-{
-    if (new_base <= f.base) return NAE_OK;
-    const size_t keep = total > new_base ? (total - new_base) * width : 0;
-    f.alt.len = 0;
-    int rc = devbuf_reserve(ctx, f.alt, keep ? keep : 1);
-    if (rc) return rc;
-    if (keep) {
-        hipError_t e = hipMemcpyAsync(f.alt.p, f.cur.p + (new_base - f.base) * width, keep * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream);
-        if (e != hipSuccess) return nae_check(ctx, e, "hipMemcpyAsync(fifo)");
-    }
-    std::swap(f.cur, f.alt);
-    f.cur.len = keep;
-    f.base = new_base;
-    return NAE_OK;
-}
-
-// make room for elements up to `want_total` (absolute), interleaved; [f.base, used_total) is live and survives a grow
-int fifo_reserve_interleaved(nae_ctx* ctx, DevFifo& f, size_t used_total, size_t want_total, size_t width)
-{
-    f.cur.len = used_total > f.base ? (used_total - f.base) * width : 0;
-    return devbuf_reserve(ctx, f.cur, (want_total > f.base ? want_total - f.base : 1) * width);
-}
 
 inline long long frame_start_host(const nae_stretch_plan& pl, long long f)
 {
@@ -425,102 +357,6 @@ int nae_stretch_destroy(nae_stretch* h)
     fifo_free(h->out);
     for (int i = 0; i < 2; i++)
         if (h->carry[i]) (void)hipFree(h->carry[i]);
-    delete h;
-    return NAE_OK;
-}
-
-// ------------------------------------------------------------------------------------------------ input conversion
-} // extern "C"
-
-struct nae_swr {
-    nae_ctx* ctx;
-    int in_fmt, in_rate, in_ch, out_rate;
-    nae_stretch* rs;          // rate stage + output FIFO (a wire when the rates are equal)
-    DevBuf raw, f32, st, outbuf;
-    bool flushed = false;
-};
-
-extern "C" {
-
-int nae_swr_create(nae_ctx* ctx, int in_fmt, int in_rate, int in_channels, int out_rate, nae_swr** h)
-{
-    if (!ctx || !h) return NAE_ERR_INVALID;
-    *h = nullptr;
-    switch (in_fmt) {
-    case NAE_FMT_S16: case NAE_FMT_S32: case NAE_FMT_FLT: case NAE_FMT_S16P: case NAE_FMT_S32P: case NAE_FMT_FLTP: break;
-    default: return nae_fail(ctx, NAE_ERR_UNSUPPORTED, "Unsupported sample format");
-    }
-    if (in_channels != 1 && in_channels != 2) return nae_fail(ctx, NAE_ERR_INVALID, "channel count must be 1 or 2");
-    if (in_rate <= 0 || out_rate <= 0) return nae_fail(ctx, NAE_ERR_INVALID, "sample rates must be positive");
-    nae_swr* s = new (std::nothrow) nae_swr();
-    if (!s) return NAE_ERR_NOMEM;
-    s->ctx = ctx; s->in_fmt = in_fmt; s->in_rate = in_rate; s->in_ch = in_channels; s->out_rate = out_rate;
-    // sample_rate 0 lifts the 8..48 kHz envelope of the SoundTouch-shaped handle: this one only transposes
-    const int rc = nae_stretch_create(ctx, 0, 2, (float)((double)in_rate / (double)out_rate), 1.0f, &s->rs);
-    if (rc) { delete s; return rc; }
-    *h = s;
-    return NAE_OK;
-}
-
-size_t nae_swr_buffered(nae_swr* h) { return h ? nae_stretch_available(h->rs) : 0; }
-
-int nae_swr_convert_host(nae_swr* h, const void* const* planes, size_t n_in, float* outL, float* outR, size_t max_out, size_t* n_out)
-{
-    if (!h || !n_out || (max_out && (!outL || !outR))) return NAE_ERR_INVALID;
-    nae_ctx* ctx = h->ctx;
-    *n_out = 0;
-    int rc;
-    if (planes && n_in) {
-        if (h->flushed) return nae_fail(ctx, NAE_ERR_STATE, "input after drain");
-        const bool planar = (h->in_fmt == NAE_FMT_FLTP || h->in_fmt == NAE_FMT_S16P || h->in_fmt == NAE_FMT_S32P);
-        const int bps = (h->in_fmt == NAE_FMT_S16 || h->in_fmt == NAE_FMT_S16P) ? 2 : 4;
-        const int n_planes = planar ? h->in_ch : 1;
-        const size_t plane_bytes = n_in * bps * (planar ? 1 : h->in_ch);
-        const size_t stride = (plane_bytes + 255) / 256 * 256;
-        if ((rc = devbuf_reserve(ctx, h->raw, stride * n_planes / sizeof(float) + 64))) return rc;
-        if ((rc = devbuf_reserve(ctx, h->f32, n_in * h->in_ch))) return rc;
-        unsigned char* raw = reinterpret_cast<unsigned char*>(h->raw.p);
-        const void* dp[2] = {raw, raw + stride};
-        for (int p = 0; p < n_planes; p++) {
-            if (!planes[p]) return nae_fail(ctx, NAE_ERR_INVALID, "null plane pointer");
-            hipError_t e = hipMemcpyAsync(raw + p * stride, planes[p], plane_bytes, hipMemcpyHostToDevice, ctx->stream);
-            if (e != hipSuccess) return nae_check(ctx, e, "hipMemcpyAsync(swr in)");
-        }
-        if ((rc = nae_to_f32_interleaved(ctx, h->in_fmt, dp, n_in, h->in_ch, h->f32.p))) return rc;
-        const float* stereo = h->f32.p;
-        if (h->in_ch == 1) {
-            if ((rc = devbuf_reserve(ctx, h->st, 2 * n_in))) return rc;
-            if ((rc = nae_mono_to_stereo_f32(ctx, h->f32.p, h->st.p, n_in, 0.70710678118654752440f))) return rc;
-            stereo = h->st.p;
-        }
-        (void)hipStreamSynchronize(ctx->stream);     // the caller's planes may be reused
-        if ((rc = nae_stretch_put(h->rs, stereo, n_in))) return rc;
-    } else if (!planes) {
-        h->flushed = true;
-        if ((rc = nae_stretch_flush(h->rs))) return rc;
-    }
-    size_t n = nae_stretch_available(h->rs);
-    if (n > max_out) n = max_out;
-    if (n == 0) return NAE_OK;
-    if ((rc = devbuf_reserve(ctx, h->outbuf, 4 * n))) return rc;      // [interleaved 2n][planar 2n]
-    size_t got = 0;
-    if ((rc = nae_stretch_receive(h->rs, h->outbuf.p, n, &got))) return rc;
-    float* planes_out[2] = {h->outbuf.p + 2 * n, h->outbuf.p + 3 * n};
-    if ((rc = nae_deinterleave_f32(ctx, h->outbuf.p, planes_out, got, 2))) return rc;
-    hipError_t e = hipMemcpyAsync(outL, planes_out[0], got * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(outR, planes_out[1], got * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) return nae_check(ctx, e, "swr out");
-    *n_out = got;
-    return NAE_OK;
-}
-
-int nae_swr_destroy(nae_swr* h)
-{
-    if (!h) return NAE_OK;
-    (void)hipStreamSynchronize(h->ctx->stream);
-    nae_stretch_destroy(h->rs);
-    devbuf_free(h->raw); devbuf_free(h->f32); devbuf_free(h->st); devbuf_free(h->outbuf);
     delete h;
     return NAE_OK;
 }

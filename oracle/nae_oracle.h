@@ -114,6 +114,23 @@ size_t orc_st_out_bound(size_t L, double rate, double pitch);
 int orc_st_process_f32(const float* src_interleaved, size_t L, int ch, int sample_rate, double rate, double pitch,
                        float* dst, size_t* out_len);
 
+/* ---- N2 input resampler (orc_swr.c): libswresample's default polyphase resampler, restated.  PARITY UNPINNED. ---- */
+typedef struct orc_swr_plan {
+    int in_rate, out_rate;
+    int filter_length, filter_alloc, phase_count;
+    int src_incr, dst_incr_div, dst_incr_mod;
+    long long index0;      /* position of output 0 in 1/phase_count input samples: -phase_count * ((filter_length - 1) / 2) */
+    double factor;
+} orc_swr_plan;
+int orc_swr_plan_make(int in_rate, int out_rate, orc_swr_plan* plan);              /* 0, -1 invalid, -2 unsupported ratio */
+void orc_swr_build_filter(const orc_swr_plan* plan, float* bank /* [phase_count][filter_alloc] */);
+void orc_swr_position(const orc_swr_plan* plan, uint64_t n, long long* first_sample, int* phase);
+size_t orc_swr_reflection(const orc_swr_plan* plan, size_t n_in);
+size_t orc_swr_outputs_upto(const orc_swr_plan* plan, size_t n_avail);
+size_t orc_swr_out_len(const orc_swr_plan* plan, size_t n_in);
+size_t orc_swr_resample_f32(const orc_swr_plan* plan, const float* bank, const float* x, size_t n_in, size_t stride, float* out,
+                            size_t out_stride);
+
 /* ---- synthetic inputs: splitmix64(seed) -> u32 -> float(u>>8)*2^-23 - 1 ---- */
 void orc_fill_uniform(float* dst, size_t n, uint64_t seed);
 

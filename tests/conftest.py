@@ -16,7 +16,7 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden():
     d = os.path.join(ROOT, "tests", "golden")
-    return {name: np.load(os.path.join(d, name + ".npz")) for name in ("nodes", "spectrum", "k7_regression", "k7_golden", "wsola_golden")}
+    return {name: np.load(os.path.join(d, name + ".npz")) for name in ("nodes", "spectrum", "k7_regression", "k7_golden", "wsola_golden", "swr_golden")}
 
 
 @pytest.fixture(scope="session")

@@ -358,18 +358,21 @@ static void test_gpu_amix_converted_input()
 	const bool ok = r.run();
 	CHECK(ok, "amix with a 44.1 kHz mono s16 input runs: " << r.get_processor_resources().at(3)->error_text);
 	if (!ok) return;
-	// expected second input: K6 (s16 / 32768) -> m/sqrt(2) on both channels -> transposer at 44100/48000
+	// expected second input: K6 (s16 / 32768) -> m/sqrt(2) on both channels -> swr's default polyphase resampler 44.1k -> 48k
 	std::vector<int16_t> q(S2);
 	for (int i = 0; i < S2; i++) q[i] = (int16_t)std::lrintf(b->samples[i] * 32767.0f);
-	std::vector<float> f(S2), st(2 * (size_t)S2);
+	std::vector<float> f(S2), st(S2);
 	const void* pl[1] = {q.data()};
 	orc_to_f32_interleaved(ORC_FMT_S16, pl, S2, 1, f.data());
-	for (int i = 0; i < S2; i++) st[2 * i] = st[2 * i + 1] = f[i] * 0.70710678118654752440f;
-	const float rate = (float)(44100.0 / 48000.0);
-	orc_stretch_plan plan;
-	orc_stretch_plan_make((double)rate, 1.0, S2, &plan);
-	std::vector<float> conv(plan.out_len * 2);
-	orc_stretch_f32(st.data(), S2, 2, (double)rate, 1.0, conv.data());
+	for (int i = 0; i < S2; i++) st[i] = f[i] * 0.70710678118654752440f;
+	orc_swr_plan swr;
+	orc_swr_plan_make(44100, 48000, &swr);
+	std::vector<float> bank((size_t)swr.phase_count * swr.filter_alloc);
+	orc_swr_build_filter(&swr, bank.data());
+	struct { size_t out_len; } plan{orc_swr_out_len(&swr, S2)};
+	std::vector<float> mono(plan.out_len), conv(plan.out_len * 2);
+	orc_swr_resample_f32(&swr, bank.data(), st.data(), S2, 1, mono.data(), 1);
+	for (size_t i = 0; i < plan.out_len; i++) conv[2 * i] = conv[2 * i + 1] = mono[i];
 	// walk the mixer output: every sample = a*0.5 + b*0.5 with b from `conv` (zero once it is exhausted)
 	size_t pos = 0;
 	bool same = true;

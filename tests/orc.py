@@ -20,6 +20,12 @@ class Plan(C.Structure):
                 ("out_len", C.c_size_t), ("mid_len", C.c_size_t), ("frames", C.c_size_t), ("rs_first", C.c_int)]
 
 
+class SwrPlan(C.Structure):
+    _fields_ = [("in_rate", C.c_int), ("out_rate", C.c_int), ("filter_length", C.c_int), ("filter_alloc", C.c_int),
+                ("phase_count", C.c_int), ("src_incr", C.c_int), ("dst_incr_div", C.c_int), ("dst_incr_mod", C.c_int),
+                ("index0", C.c_longlong), ("factor", C.c_double)]
+
+
 _lib = None
 
 
@@ -60,6 +66,14 @@ def lib():
         L.orc_st_aa_coef.restype = C.POINTER(C.c_float)
         L.orc_st_aa_coef.argtypes = [C.c_void_p]
         L.orc_st_cubic_weights.argtypes = [C.c_float, C.c_void_p]
+        L.orc_swr_plan_make.argtypes = [C.c_int, C.c_int, C.POINTER(SwrPlan)]
+        L.orc_swr_build_filter.argtypes = [C.POINTER(SwrPlan), C.c_void_p]
+        L.orc_swr_out_len.restype = C.c_size_t
+        L.orc_swr_out_len.argtypes = [C.POINTER(SwrPlan), C.c_size_t]
+        L.orc_swr_outputs_upto.restype = C.c_size_t
+        L.orc_swr_outputs_upto.argtypes = [C.POINTER(SwrPlan), C.c_size_t]
+        L.orc_swr_resample_f32.restype = C.c_size_t
+        L.orc_swr_resample_f32.argtypes = [C.POINTER(SwrPlan), C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t]
         _lib = L
     return _lib
 
@@ -274,6 +288,31 @@ def st_process(x, ch, sample_rate, rate, pitch, chunk=None, want_offsets=False):
     st.close()
     y = np.concatenate(outs) if outs else np.zeros(0, np.float32)
     return (y, offs) if want_offsets else y
+
+
+def swr_plan(in_rate, out_rate):
+    pl = SwrPlan()
+    rc = lib().orc_swr_plan_make(in_rate, out_rate, C.byref(pl))
+    return rc, pl
+
+
+def swr_bank(pl):
+    bank = np.empty((pl.phase_count, pl.filter_alloc), np.float32)
+    lib().orc_swr_build_filter(C.byref(pl), _p(bank))
+    return bank
+
+
+def swr_resample(x, in_rate, out_rate):
+    """one channel, whole signal including what a drain delivers (N2 spec: oracle/orc_swr.c)"""
+    x = np.ascontiguousarray(x, np.float32)
+    rc, pl = swr_plan(in_rate, out_rate)
+    assert rc == 0, rc
+    bank = swr_bank(pl)
+    n_out = lib().orc_swr_out_len(C.byref(pl), x.size)
+    out = np.empty(max(n_out, 1), np.float32)
+    got = lib().orc_swr_resample_f32(C.byref(pl), _p(bank), _p(x), x.size, 1, _p(out), 1)
+    assert got == n_out
+    return out[:n_out]
 
 
 def fill_uniform(n, seed):

@@ -3,6 +3,7 @@ import numpy as np
 import pytest
 
 import orc
+from conftest import rel_rms
 
 pytestmark = pytest.mark.gpu
 
@@ -280,7 +281,7 @@ def test_fill_uniform_matches_oracle_generator(ctx):
 
 def test_n2_input_conversion(ctx, nae):
     """nae_swr: identity input is a bit copy; mono s16 at 44.1 kHz -> 48 kHz stereo equals the oracle composition
-    K6 -> m/sqrt(2) -> transposer (builder-defined: unpinned versus libswresample)"""
+    K6 -> m/sqrt(2) -> libswresample-default polyphase resampler (restated: unpinned versus FFmpeg itself)"""
     import ctypes as C
     lib = ctx.lib
     # --- identity: 48 kHz stereo FLT in uneven chunks, swr_convert semantics (max_out smaller than what is buffered)
@@ -306,7 +307,7 @@ def test_n2_input_conversion(ctx, nae):
     assert lib.nae_swr_destroy(h) == 0
     assert_bits(np.concatenate(outL), x[0::2].copy(), "identity L")
     assert_bits(np.concatenate(outR), x[1::2].copy(), "identity R")
-    # --- mono s16 @ 44.1 kHz
+    # --- mono s16 @ 44.1 kHz, one put + drain: K6 scaling, m / sqrt(2), then the swr-default polyphase resampler
     n = 22050
     m = (orc.fill_uniform(n, 72) * 30000).astype(np.int16)
     assert lib.nae_swr_create(ctx.h, nae.FMT_S16, 44100, 1, 48000, C.byref(h)) == 0
@@ -315,19 +316,62 @@ def test_n2_input_conversion(ctx, nae):
     L, R = np.zeros(cap, np.float32), np.zeros(cap, np.float32)
     assert lib.nae_swr_convert_host(h, planes, n, L.ctypes.data, R.ctypes.data, cap, C.byref(got)) == 0
     k1 = got.value
-    assert 0 < k1 < 24000
+    assert 0 < k1 < 24000                                # the last half filter length waits for the drain
     assert lib.nae_swr_convert_host(h, None, 0, L[k1:].ctypes.data, R[k1:].ctypes.data, cap - k1, C.byref(got)) == 0
     total = k1 + got.value
     assert lib.nae_swr_destroy(h) == 0
     rc, f = orc.to_f32_interleaved(orc.FMT_S16, [m], n, 1)
     st = (f * np.float32(0.70710678118654752440)).astype(np.float32)
-    rate = float(np.float32(44100.0 / 48000.0))
-    ref = orc.stretch(np.stack([st, st], 1).reshape(-1), 2, rate, 1.0)
-    assert total == ref.size // 2 == 24000
-    assert_bits(L[:total].copy(), ref[0::2].copy(), "resampled L")      # the transposer is bit-exact vs the oracle
-    assert_bits(R[:total].copy(), ref[1::2].copy(), "resampled R")
+    ref = orc.swr_resample(st, 44100, 48000)
+    assert total == ref.size == 24000
+    assert_bits(L[:total].copy(), ref, "resampled L")                    # bit-exact vs the oracle (oracle/orc_swr.c)
+    assert_bits(R[:total].copy(), ref, "resampled R")
     assert lib.nae_swr_create(ctx.h, 4, 48000, 2, 48000, C.byref(h)) == -2     # AV_SAMPLE_FMT_DBL
     assert lib.nae_swr_create(ctx.h, nae.FMT_FLT, 48000, 6, 48000, C.byref(h)) == -1
+
+
+def swr_drive(ctx, nae, fmt, in_rate, ch, planes_of, n_total, chunks, max_out=4096):
+    """swr_convert-style driving of nae_swr: put the chunks (receiving at most max_out frames per call), then drain"""
+    import ctypes as C
+    lib = ctx.lib
+    h, got = C.c_void_p(), C.c_size_t()
+    assert lib.nae_swr_create(ctx.h, fmt, in_rate, ch, 48000, C.byref(h)) == 0
+    outL, outR, pos, i = [], [], 0, 0
+    while pos < n_total:
+        n = min(chunks[i % len(chunks)], n_total - pos)
+        arrs = planes_of(pos, n)
+        planes = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        L, R = np.zeros(max_out, np.float32), np.zeros(max_out, np.float32)
+        assert lib.nae_swr_convert_host(h, planes, n, L.ctypes.data, R.ctypes.data, max_out, C.byref(got)) == 0
+        outL.append(L[: got.value].copy()); outR.append(R[: got.value].copy())
+        pos += n
+        i += 1
+    while True:
+        L, R = np.zeros(max_out, np.float32), np.zeros(max_out, np.float32)
+        assert lib.nae_swr_convert_host(h, None, 0, L.ctypes.data, R.ctypes.data, max_out, C.byref(got)) == 0
+        if got.value == 0:
+            break
+        outL.append(L[: got.value].copy()); outR.append(R[: got.value].copy())
+    assert lib.nae_swr_destroy(h) == 0
+    return np.concatenate(outL), np.concatenate(outR)
+
+
+@pytest.mark.parametrize("in_rate", [44100, 22050, 96000, 8000])
+def test_n2_resampler_golden_and_chunking(ctx, nae, golden, in_rate):
+    """the swr-default resampler on the golden signals: bit-exact vs the oracle, <= 1e-4 relative RMS vs the float64
+    golden (tests/golden/swr_numpy.py), and independent of how the input is cut into swr_convert calls"""
+    g = golden["swr_golden"]
+    for name in ("tones", "noise", "impulse"):
+        x, ref64 = g[name + "_in"], g[f"{name}_{in_rate}_48000"]
+        st = np.stack([x, -x], 1).reshape(-1).astype(np.float32)            # stereo FLT: R = -L
+        for chunks in ([6000], [1152, 1152, 577, 3001], [64, 1, 700]):
+            L, R = swr_drive(ctx, nae, nae.FMT_FLT, in_rate, 2, lambda p, n: [np.ascontiguousarray(st[2 * p: 2 * (p + n)])], x.size, chunks,
+                             max_out=1500)
+            ref = orc.swr_resample(x, in_rate, 48000)
+            assert_bits(L, ref, f"{name} {in_rate} L chunks {chunks[:2]}")
+            assert_bits(R, orc.swr_resample(-x, in_rate, 48000), f"{name} {in_rate} R")
+            assert L.size == ref64.size
+        assert rel_rms(L, ref64) <= 1e-4
 
 
 def test_many_streams_and_empty_calls(ctx, nae):

@@ -229,3 +229,29 @@ def test_k7_parameter_envelope():
     assert rc == 0 and pl.pv_on and not pl.rs_on and pl.out_len == 500
     rc, pl = orc.plan(1.0, 1.0, 0)
     assert rc == 0 and pl.out_len == 0
+
+
+@pytest.mark.parametrize("in_rate", [44100, 22050, 96000, 8000])
+def test_n2_swr_oracle_matches_float64_golden(golden, in_rate):
+    """oracle/orc_swr.c (libswresample's default resampler, restated; UNPINNED versus FFmpeg) against the independent float64
+    restatement of the same specification (tests/golden/swr_numpy.py): same output count, <= 1e-4 relative RMS"""
+    g = golden["swr_golden"]
+    for name in ("tones", "noise", "impulse"):
+        y = orc.swr_resample(g[name + "_in"], in_rate, 48000)
+        ref = g[f"{name}_{in_rate}_48000"]
+        assert y.size == ref.size
+        assert rel_rms(y, ref) <= 1e-4
+
+
+def test_n2_swr_plan_and_edges():
+    rc, pl = orc.swr_plan(44100, 48000)
+    assert rc == 0 and (pl.filter_length, pl.phase_count, pl.src_incr, pl.dst_incr_div, pl.dst_incr_mod) == (32, 1024, 5, 940, 4)
+    rc, pl = orc.swr_plan(96000, 48000)                     # down-conversion: the filter stretches by 1 / (0.5 * 0.97)
+    assert rc == 0 and pl.filter_length == 66
+    assert orc.swr_plan(48000, 1000)[0] == -2                # 48x down: beyond NAE_SWR_MAX_TAPS
+    assert orc.swr_resample(np.zeros(0, np.float32), 44100, 48000).size == 0
+    # unit DC gain of every phase; a constant stays that constant away from the ends and, thanks to the reflection, at them
+    y = orc.swr_resample(np.full(4000, 0.25, np.float32), 44100, 48000)
+    assert y.size == 4354 and np.abs(y - 0.25).max() < 1e-6
+    # one second in -> one second out
+    assert orc.swr_resample(np.zeros(44100, np.float32), 44100, 48000).size == 48000
