@@ -51,7 +51,9 @@ typedef struct nae_spectrum nae_spectrum;
 /* ------------------------------------------------------------------ context / plumbing */
 int nae_abi_version(void);
 int nae_device_count(void);
-int nae_ctx_create(int device, nae_ctx** out);          /* one per GPU (one per process in the sharded bench) */
+/* One GPU per process: every context of a process must name the same device (a second device returns
+ * NAE_ERR_UNSUPPORTED); several contexts on that device are fine — each has its own stream, so their work overlaps. */
+int nae_ctx_create(int device, nae_ctx** out);
 int nae_ctx_destroy(nae_ctx* ctx);
 int nae_ctx_set_stream(nae_ctx* ctx, void* hip_stream); /* borrow a hipStream_t (e.g. torch's current stream) */
 void* nae_ctx_stream(nae_ctx* ctx);
@@ -62,6 +64,10 @@ const char* nae_device_name(nae_ctx* ctx);
 
 int nae_malloc(nae_ctx* ctx, size_t bytes, void** dptr);
 int nae_free(nae_ctx* ctx, void* dptr);
+/* page-locked host memory (hipHostMalloc): copies to and from it are truly asynchronous and run at the full PCIe rate, so
+ * uploads, kernels and downloads of consecutive batches can overlap on two contexts / streams */
+int nae_malloc_host(nae_ctx* ctx, size_t bytes, void** hptr);
+int nae_free_host(nae_ctx* ctx, void* hptr);
 int nae_memcpy_h2d(nae_ctx* ctx, void* dst, const void* src_host, size_t bytes); /* async on the ctx stream */
 int nae_memcpy_d2h(nae_ctx* ctx, void* dst_host, const void* src, size_t bytes); /* async on the ctx stream */
 int nae_memcpy_d2d(nae_ctx* ctx, void* dst, const void* src, size_t bytes);

@@ -19,7 +19,7 @@ EXPORTED_SYMBOLS = [
     "nae_ctx_stream", "nae_sync", "nae_poll", "nae_last_error", "nae_device_name", "nae_malloc", "nae_free",
     "nae_memcpy_h2d", "nae_memcpy_d2h", "nae_memcpy_d2d", "nae_memset", "nae_event_create", "nae_event_record",
     "nae_event_elapsed_ms", "nae_event_destroy", "nae_prof_enable", "nae_prof_reset", "nae_prof_get",
-    "nae_debug_clock_ghz", "nae_debug_diff_u32", "nae_fill_uniform_f32", "nae_gain_f32", "nae_gain_s16", "nae_gain_s32", "nae_gain_frame",
+    "nae_malloc_host", "nae_free_host", "nae_debug_clock_ghz", "nae_debug_diff_u32", "nae_fill_uniform_f32", "nae_gain_f32", "nae_gain_s16", "nae_gain_s32", "nae_gain_frame",
     "nae_deinterleave_f32", "nae_interleave_f32", "nae_copy_sig_f32", "nae_gain_sig_f32", "nae_amix_f32",
     "nae_amix_sig_f32", "nae_bimix_f32", "nae_bimix2_downmix_f32", "nae_bimix2_interleave_f32",
     "nae_to_f32_interleaved", "nae_clamp_f32", "nae_stretch_plan_make", "nae_stretch_block_f32",
@@ -116,6 +116,7 @@ def load_library() -> C.CDLL:
         "nae_event_elapsed_ms": (i, [vp, vp, P(f)]), "nae_event_destroy": (i, [vp]),
         "nae_prof_enable": (i, [vp, i]), "nae_prof_reset": (i, [vp]),
         "nae_prof_get": (i, [vp, i, C.c_char_p, sz, P(d), P(C.c_uint64)]),
+        "nae_malloc_host": (i, [vp, sz, P(vp)]), "nae_free_host": (i, [vp, vp]),
         "nae_debug_clock_ghz": (i, [vp, P(C.c_double)]),
         "nae_debug_diff_u32": (i, [vp, vp, vp, sz, vp]),
         "nae_fill_uniform_f32": (i, [vp, vp, sz, sz, sz, C.c_uint64, C.c_uint64]),
@@ -223,6 +224,7 @@ class Context:
         self.h = h
         self.device = device
         self._allocs = set()
+        self._pinned = {}
 
     # -- plumbing
     def _ck(self, rc: int) -> None:
@@ -294,6 +296,23 @@ class Context:
             self.lib.nae_prof_get(self.h, k, name, 128, C.byref(ms), C.byref(cnt))
             out[name.value.decode()] = (ms.value, cnt.value)
         return out
+
+    def pinned(self, shape, dtype=np.float32) -> np.ndarray:
+        """numpy view of page-locked host memory (nae_malloc_host); release with free_pinned(array)"""
+        shape = tuple(int(x) for x in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        self._ck(self.lib.nae_malloc_host(self.h, max(nbytes, 16), C.byref(p)))
+        buf = (C.c_char * max(nbytes, 16)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape, dtype=np.int64))).reshape(shape)
+        self._pinned[arr.ctypes.data] = p.value
+        return arr
+
+    def free_pinned(self, arr: np.ndarray) -> None:
+        p = self._pinned.pop(arr.ctypes.data, None)
+        if p:
+            self.sync()
+            self.lib.nae_free_host(self.h, p)
 
     def diff_words(self, a: int, b: int, n_words: int, d_count: int) -> None:
         """adds the number of differing 32-bit words of device buffers a, b to the device uint64 at d_count (asynchronous)"""

@@ -60,6 +60,7 @@ static void prof_collect(nae_ctx* ctx)
 int nae_ws_reserve(nae_ctx* ctx, void** p, size_t* have, size_t want)
 {
     if (*have >= want && *p) return NAE_OK;
+    (void)hipSetDevice(ctx->device);
     if (*p) {
         hipError_t e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) return nae_check(ctx, e, "hipStreamSynchronize");
@@ -177,6 +178,12 @@ int nae_device_count(void)
     return n;
 }
 
+// One GPU per process (the deployment model: one process per GPU, torch.distributed / RCCL between them).  Allocations and
+// launches go to the calling thread's CURRENT device, so contexts on two devices inside one process would need a device
+// switch at every entry point; instead a second device is refused, and the entry points that allocate re-select the
+// context's device in case another library (torch) changed the thread's current one.
+static int g_nae_device = -1;
+
 int nae_ctx_create(int device, nae_ctx** out)
 {
     if (!out) return NAE_ERR_INVALID;
@@ -184,7 +191,9 @@ int nae_ctx_create(int device, nae_ctx** out)
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return NAE_ERR_HIP;
     if (device < 0 || device >= n) return NAE_ERR_INVALID;
+    if (g_nae_device >= 0 && g_nae_device != device) return NAE_ERR_UNSUPPORTED;
     if (hipSetDevice(device) != hipSuccess) return NAE_ERR_HIP;
+    g_nae_device = device;
     nae_ctx* ctx = new (std::nothrow) nae_ctx();
     if (!ctx) return NAE_ERR_NOMEM;
     ctx->device = device;
@@ -266,6 +275,7 @@ int nae_malloc(nae_ctx* ctx, size_t bytes, void** dptr)
     if (!ctx || !dptr) return NAE_ERR_INVALID;
     *dptr = nullptr;
     if (bytes == 0) bytes = 16;
+    (void)hipSetDevice(ctx->device);
     hipError_t e = hipMalloc(dptr, bytes);
     if (e != hipSuccess) { nae_check(ctx, e, "hipMalloc"); return NAE_ERR_NOMEM; }
     return NAE_OK;
@@ -274,6 +284,21 @@ int nae_free(nae_ctx* ctx, void* dptr)
 {
     if (!dptr) return NAE_OK;
     return nae_check(ctx, hipFree(dptr), "hipFree");
+}
+int nae_malloc_host(nae_ctx* ctx, size_t bytes, void** hptr)
+{
+    if (!ctx || !hptr) return NAE_ERR_INVALID;
+    *hptr = nullptr;
+    if (bytes == 0) bytes = 16;
+    (void)hipSetDevice(ctx->device);
+    hipError_t e = hipHostMalloc(hptr, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) { nae_check(ctx, e, "hipHostMalloc"); return NAE_ERR_NOMEM; }
+    return NAE_OK;
+}
+int nae_free_host(nae_ctx* ctx, void* hptr)
+{
+    if (!hptr) return NAE_OK;
+    return nae_check(ctx, hipHostFree(hptr), "hipHostFree");
 }
 int nae_memcpy_h2d(nae_ctx* ctx, void* dst, const void* src, size_t bytes)
 {

@@ -546,6 +546,11 @@ static int wsola_append(nae_wsola* h, const float* p, size_t S, bool host)
     hipError_t e = hipMemcpyAsync(h->in.p + (size_t)(h->in.total - h->in.base) * (size_t)h->in.w, p, S * (size_t)h->in.w * sizeof(float),
                                   host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, ctx->stream);
     if (e != hipSuccess) return nae_check(ctx, e, "hipMemcpyAsync(put)");
+    if (host) {
+        // the caller may reuse its buffer as soon as the call returns (with pinned memory the copy is truly asynchronous)
+        e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) return nae_check(ctx, e, "hipStreamSynchronize(put)");
+    }
     h->in.total += (long long)S;
     h->in_real = h->in.total;
     const StState before = h->st;

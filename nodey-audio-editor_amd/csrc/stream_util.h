@@ -15,6 +15,7 @@ static inline int devbuf_reserve(nae_ctx* ctx, DevBuf& b, size_t want)
     size_t cap = b.cap ? b.cap : 1 << 16;
     while (cap < want) cap *= 2;
     float* np = nullptr;
+    (void)hipSetDevice(ctx->device);
     if (hipMalloc((void**)&np, cap * sizeof(float)) != hipSuccess) return nae_fail(ctx, NAE_ERR_NOMEM, "hipMalloc(stream buffer)");
     if (b.len) {
         hipError_t e = hipMemcpyAsync(np, b.p, b.len * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream);

@@ -138,3 +138,9 @@ namespace infra
 
 	void register_all_processors();
 }
+namespace processor { enum class Stretch_algorithm; }
+namespace infra
+{
+	// same, choosing what velocity_modifier / pitch_modifier nodes WITHOUT an "algorithm" key run (processor/audio-velocity.hpp)
+	void register_all_processors(processor::Stretch_algorithm default_algorithm);
+}

@@ -1,4 +1,6 @@
 #include "audio-mix.hpp"
+#include "bimix-align.hpp"
+#include <deque>
 #include "gpu-context.hpp"
 
 #include <algorithm>
@@ -344,9 +346,10 @@ namespace processor
 	}
 	std::vector<infra::Processor::Pin_attribute> Audio_bimix_v2::get_pin_attributes() const { return lr_pins(); }
 
-	// control flow of audio-bimix.cpp:475-877.  GPU calls: downmix (:624-627,717-720) and interleave with zero
-	// fill (:797-803, :833-850, :736-742, :759-765).  The pts-alignment bookkeeping (:777-872) is host logic, kept
-	// statement for statement.
+	// Audio_bimix_v2 (audio-bimix.cpp:475-877): each input is converted to 48 kHz, mixed down to mono on the GPU
+	// (:624-627, :717-720) and queued with its presentation time; the two queues are then lined up on those times
+	// (bimix-align.hpp) and every step leaves as one interleaved stereo frame built on the GPU — the side that is not playing
+	// is silent (:797-803, :833-850, :736-742, :759-765).
 	void Audio_bimix_v2::process_payload(
 		const std::map<std::string, std::shared_ptr<infra::Processor::Product>>& input,
 		const std::map<std::string, std::set<std::shared_ptr<infra::Processor::Product>>>& output,
@@ -354,165 +357,142 @@ namespace processor
 		std::any&
 	)
 	{
-		auto input_item_optional_l = infra::get_input_item<Audio_stream>(input, "input_l");
-		auto input_item_optional_r = infra::get_input_item<Audio_stream>(input, "input_r");
-		if (!input_item_optional_l.has_value() || !input_item_optional_r.has_value())
+		auto in_l = infra::get_input_item<Audio_stream>(input, "input_l");
+		auto in_r = infra::get_input_item<Audio_stream>(input, "input_r");
+		if (!in_l.has_value() || !in_r.has_value())
 			throw Runtime_error(
 				"Audio Channel mix processor has no input",
 				"Audio channel mix processor requires an audio stream input to function properly.",
 				"Input item 'input' not found"
 			);
-		auto& input_stream_l = input_item_optional_l.value().get();
-		auto& input_stream_r = input_item_optional_r.value().get();
 		auto output_stream = infra::get_output_item<Audio_stream>(output, "output");
-		constexpr auto target_sample_rate = 48000;  // config::processor::audio_bimix::std_sample_rate
-
-		struct Frame
-		{
-			std::vector<float> samples;
-			double time_seconds = 0.0;
-			double elapsed_seconds() const { return double(samples.size()) / target_sample_rate; }
-			double end_time() const { return time_seconds + elapsed_seconds(); }
-			void drop_samples(size_t count)
-			{
-				samples.erase(samples.begin(), samples.begin() + count);
-				time_seconds += double(count) / target_sample_rate;
-			}
-		};
-		std::list<Frame> frames_l, frames_r;
-		bool have_l = false, have_r = false;
-		double time_l = 0, time_r = 0;
-		bool eof_l = false, eof_r = false;
+		constexpr int rate = 48000;  // config::processor::audio_bimix::std_sample_rate
 		nae_ctx* ctx = gpu::context();
 		gpu::Device_buffer d_a, d_b, d_out;
 
-		// one side's intake: "resample" (identity) + mono downmix on the GPU
-		Gpu_swr resampler_l, resampler_r;
-		auto intake = [&](Audio_stream& stream, bool& eof, bool& have, double& t, std::list<Frame>& frames, Gpu_swr& resampler)
+		// a mono block waiting to be placed: samples [at, mono.size()) are pending, the first of them plays at `begin`
+		struct Pending
 		{
-			if (eof) return;
-			const auto pop_result = stream.try_pop();
-			if (!pop_result.has_value())
+			std::vector<float> mono;
+			size_t at = 0;
+			double begin = 0.0;
+			bimix::Span span() const { return {begin, mono.size() - at}; }
+			const float* data() const { return mono.data() + at; }
+			void play(size_t n) { at += n; begin += double(n) / rate; }
+		};
+		struct Side
+		{
+			Audio_stream& stream;
+			Gpu_swr resampler;
+			std::deque<Pending> queue;
+			bool opened = false, ended = false;
+			double clock = 0.0;  // presentation time behind the last sample delivered by the resampler
+			explicit Side(Audio_stream& s) : stream(s) {}
+		};
+		Side side[2] = {Side(in_l.value().get()), Side(in_r.value().get())};
+
+		// take one frame off an input: convert, advance the side's clock by what the converter delivered (:594-618: a block is
+		// stamped with the time BEHIND it), mix it down to mono on the GPU and queue it
+		auto intake = [&](Side& sd)
+		{
+			if (sd.ended) return;
+			const auto popped = sd.stream.try_pop();
+			if (!popped.has_value())
 			{
-				if (pop_result.error() == channel_op_status::empty && stream.eof()) eof = true;
+				if (popped.error() == channel_op_status::empty && sd.stream.eof()) sd.ended = true;
 				return;
 			}
-			const auto& data = *pop_result.value()->data();
+			const auto& data = *popped.value()->data();
 			if (data.ch_layout.nb_channels != 2 && data.ch_layout.nb_channels != 1)
 				throw Runtime_error("Invalid audio channel layout", "Audio channel layout must be stereo or mono.",
 									infra::fmt("Invalid channel layout: %d", data.ch_layout.nb_channels));
-			if (!have)
+			if (!sd.opened)
 			{
-				have = true;
-				resampler.open(data);                   // :563-588
-				t = data.pts * av_q2d(data.time_base);  // :589
+				sd.opened = true;
+				sd.resampler.open(data);
+				sd.clock = data.pts * av_q2d(data.time_base);
 			}
-			// :594-604: resample into buffers of 2*nb_samples; the count delivered advances the clock
-			std::vector<float> l(2 * (size_t)data.nb_samples + 1, 0.0f), r(2 * (size_t)data.nb_samples + 1, 0.0f);
-			const int n = resampler.convert(&data, l.data(), r.data(), 2 * data.nb_samples);
-			t += double(n) / target_sample_rate;  // :618 — the frame is stamped with its END time
+			const size_t room = 2 * (size_t)data.nb_samples;
+			std::vector<float> l(room + 1, 0.0f), r(room + 1, 0.0f);
+			const int n = sd.resampler.convert(&data, l.data(), r.data(), (int)room);
+			sd.clock += double(n) / rate;
 			if (n == 0) return;
-			Frame new_frame;
-			new_frame.time_seconds = t;
-			new_frame.samples.resize(n);
+			Pending block;
+			block.begin = sd.clock;
+			block.mono.resize(n);
 			float* da = static_cast<float*>(d_a.reserve(n * sizeof(float)));
 			float* db = static_cast<float*>(d_b.reserve(n * sizeof(float)));
 			float* dm = static_cast<float*>(d_out.reserve(2 * n * sizeof(float) + 64));
 			gpu::check(nae_memcpy_h2d(ctx, da, l.data(), n * sizeof(float)), "h2d");
 			gpu::check(nae_memcpy_h2d(ctx, db, r.data(), n * sizeof(float)), "h2d");
 			gpu::check(nae_bimix2_downmix_f32(ctx, da, db, dm, n), "nae_bimix2_downmix_f32");
-			gpu::check(nae_memcpy_d2h(ctx, new_frame.samples.data(), dm, n * sizeof(float)), "d2h");
+			gpu::check(nae_memcpy_d2h(ctx, block.mono.data(), dm, n * sizeof(float)), "d2h");
 			gpu::wait(stop_token);
-			frames.emplace_back(std::move(new_frame));
+			sd.queue.emplace_back(std::move(block));
 		};
 
-		auto make_audio_frame_flt_interleaved = [&](const float* earlier, const float* later, size_t unaligned,
-													 size_t aligned, int earlier_offset, double time_seconds)
+		// one output frame: `solo` samples of side `first` alone, then `both` samples of the two sides
+		auto emit = [&](const float* first_side, const float* other_side, size_t solo, size_t both, int first, double begin)
 		{
-			const size_t n = unaligned + aligned;
-			auto frame = std::make_shared<Audio_frame>();  // :451-473
+			const size_t n = solo + both;
+			auto frame = std::make_shared<Audio_frame>();
 			Frame_data* data = frame->data();
 			data->nb_samples = (int)n;
 			data->ch_layout.nb_channels = 2;
-			data->sample_rate = target_sample_rate;
+			data->sample_rate = rate;
 			data->format = AV_SAMPLE_FMT_FLT;
-			data->pts = (int64_t)(time_seconds * 1000000);
+			data->pts = (int64_t)(begin * 1000000);
 			data->time_base = {1, 1000000};
 			frame_get_buffer(data, 32);
-			if (n == 0) return frame;
-			float* da = static_cast<float*>(d_a.reserve(n * sizeof(float)));
-			float* db = static_cast<float*>(d_b.reserve((aligned ? aligned : 1) * sizeof(float)));
-			float* dd = static_cast<float*>(d_out.reserve(2 * n * sizeof(float) + 64));
-			gpu::check(nae_memcpy_h2d(ctx, da, earlier, n * sizeof(float)), "h2d");
-			if (aligned) gpu::check(nae_memcpy_h2d(ctx, db, later, aligned * sizeof(float)), "h2d");
-			gpu::check(nae_bimix2_interleave_f32(ctx, dd, da, aligned ? db : nullptr, unaligned, aligned, earlier_offset), "nae_bimix2_interleave_f32");
-			gpu::check(nae_memcpy_d2h(ctx, data->data[0], dd, 2 * n * sizeof(float)), "d2h");
-			gpu::wait(stop_token);
-			return frame;
+			if (n)
+			{
+				float* da = static_cast<float*>(d_a.reserve(n * sizeof(float)));
+				float* db = static_cast<float*>(d_b.reserve((both ? both : 1) * sizeof(float)));
+				float* dd = static_cast<float*>(d_out.reserve(2 * n * sizeof(float) + 64));
+				gpu::check(nae_memcpy_h2d(ctx, da, first_side, n * sizeof(float)), "h2d");
+				if (both) gpu::check(nae_memcpy_h2d(ctx, db, other_side, both * sizeof(float)), "h2d");
+				gpu::check(nae_bimix2_interleave_f32(ctx, dd, da, both ? db : nullptr, solo, both, first), "nae_bimix2_interleave_f32");
+				gpu::check(nae_memcpy_d2h(ctx, data->data[0], dd, 2 * n * sizeof(float)), "d2h");
+				gpu::wait(stop_token);
+			}
+			push_to_all(output_stream, frame, stop_token);
+		};
+		auto emit_alone = [&](int which)
+		{
+			Pending& p = side[which].queue.front();
+			emit(p.data(), nullptr, p.span().count, 0, which, p.begin);
+			side[which].queue.pop_front();
 		};
 
 		while (!stop_token)
 		{
 			nae_fiber::this_fiber::yield();
-			intake(input_stream_l, eof_l, have_l, time_l, frames_l, resampler_l);
-			intake(input_stream_r, eof_r, have_r, time_r, frames_r, resampler_r);
-
-			if (frames_l.empty() && frames_r.empty() && eof_l && eof_r) break;
-			if (frames_r.empty() && eof_r)  // right ended: :732-752
+			intake(side[0]);
+			intake(side[1]);
+			const bool idle[2] = {side[0].queue.empty(), side[1].queue.empty()};
+			if (idle[0] && idle[1] && side[0].ended && side[1].ended) break;
+			// one input has ended and is drained: the other plays on alone, block by block
+			if (idle[1] && side[1].ended) { if (!idle[0]) emit_alone(0); continue; }
+			if (idle[0] && side[0].ended) { if (!idle[1]) emit_alone(1); continue; }
+			while (!side[0].queue.empty() && !side[1].queue.empty() && !stop_token)
 			{
-				if (frames_l.empty()) continue;
-				auto& f = frames_l.front();
-				push_to_all(output_stream, make_audio_frame_flt_interleaved(f.samples.data(), nullptr, f.samples.size(), 0, 0, f.time_seconds), stop_token);
-				frames_l.pop_front();
-				continue;
-			}
-			if (frames_l.empty() && eof_l)  // left ended: :755-775
-			{
-				if (frames_r.empty()) continue;
-				auto& f = frames_r.front();
-				push_to_all(output_stream, make_audio_frame_flt_interleaved(f.samples.data(), nullptr, f.samples.size(), 0, 1, f.time_seconds), stop_token);
-				frames_r.pop_front();
-				continue;
-			}
-			while (!frames_l.empty() && !frames_r.empty() && !stop_token)  // :777-872
-			{
-				const bool left_eariler = frames_l.front().time_seconds < frames_r.front().time_seconds;
-				const int eariler_offset = left_eariler ? 0 : 1;
-				auto& eariler_stream = left_eariler ? frames_l : frames_r;
-				auto& later_stream = left_eariler ? frames_r : frames_l;
-				const double eariler_begin_time = eariler_stream.front().time_seconds;
-				const double later_begin_time = later_stream.front().time_seconds;
-				const double eariler_end_time = eariler_stream.front().end_time();
-				const double later_end_time = later_stream.front().end_time();
-				if (eariler_end_time <= later_begin_time)
+				Pending* p[2] = {&side[0].queue.front(), &side[1].queue.front()};
+				const bimix::Step st = bimix::align_step(p[0]->span(), p[1]->span(), rate);
+				const int a = st.first, b = 1 - st.first;
+				const float* fa = p[a]->data();
+				const float* fb = p[b]->data();
+				const double begin = p[a]->begin;
+				// the queues change before the frame is built: its sample pointers stay valid (a deque keeps the blocks it does not
+				// remove in place, and the removed ones are moved out first)
+				Pending keep[2];
+				for (int k = 0; k < 2; k++)
 				{
-					auto& f = eariler_stream.front();
-					push_to_all(output_stream, make_audio_frame_flt_interleaved(f.samples.data(), nullptr, f.samples.size(), 0, eariler_offset, eariler_begin_time), stop_token);
-					eariler_stream.pop_front();
-					continue;
+					if (st.used_up[k]) { keep[k] = std::move(*p[k]); side[k].queue.pop_front(); }
+					else p[k]->play(st.played[k]);
 				}
-				const double frame_end_time = std::min(eariler_end_time, later_end_time);
-				const auto unaligned_samples = static_cast<size_t>(std::round((later_begin_time - eariler_begin_time) * target_sample_rate));
-				auto aligned_samples = static_cast<size_t>(std::round((frame_end_time - later_begin_time) * target_sample_rate));
-				aligned_samples = std::min(aligned_samples, eariler_stream.front().samples.size() - unaligned_samples);
-				aligned_samples = std::min(aligned_samples, later_stream.front().samples.size());
-				auto frame = make_audio_frame_flt_interleaved(
-					eariler_stream.front().samples.data(), later_stream.front().samples.data(), unaligned_samples,
-					aligned_samples, eariler_offset, eariler_begin_time
-				);
-				if (eariler_end_time <= later_end_time)
-				{
-					eariler_stream.pop_front();
-					later_stream.front().drop_samples(aligned_samples);
-				}
-				else
-				{
-					later_stream.pop_front();
-					eariler_stream.front().drop_samples(unaligned_samples + aligned_samples);
-				}
-				if (!eariler_stream.empty() && eariler_stream.front().samples.empty()) eariler_stream.pop_front();
-				if (!later_stream.empty() && later_stream.front().samples.empty()) later_stream.pop_front();
-				push_to_all(output_stream, frame, stop_token);
+				for (int k = 0; k < 2; k++)
+					if (!st.used_up[k] && p[k]->span().count == 0) { keep[k] = std::move(*p[k]); side[k].queue.pop_front(); }
+				emit(fa, fb, st.solo, st.both, a, begin);
 			}
 		}
 		for (auto& stream : output_stream) stream->set_eof();

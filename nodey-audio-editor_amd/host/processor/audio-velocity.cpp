@@ -8,11 +8,21 @@ namespace processor
 {
 	const char* algorithm_name(Stretch_algorithm a) { return a == Stretch_algorithm::Soundtouch ? "soundtouch" : "vocoder"; }
 
+	namespace
+	{
+		Stretch_algorithm g_default_algorithm = Stretch_algorithm::Vocoder;
+	}
+	Stretch_algorithm default_stretch_algorithm() { return g_default_algorithm; }
+	void set_default_stretch_algorithm(Stretch_algorithm a) { g_default_algorithm = a; }
+
 	Stretch_algorithm algorithm_from_json(const Json::Value& value)
 	{
-		if (value.isMember("algorithm") && value["algorithm"].isString() && value["algorithm"].asString() == "soundtouch")
-			return Stretch_algorithm::Soundtouch;
-		return Stretch_algorithm::Vocoder;
+		if (value.isMember("algorithm") && value["algorithm"].isString())
+		{
+			if (value["algorithm"].asString() == "soundtouch") return Stretch_algorithm::Soundtouch;
+			if (value["algorithm"].asString() == "vocoder") return Stretch_algorithm::Vocoder;
+		}
+		return default_stretch_algorithm();   // no key: a project saved by the reference
 	}
 
 	namespace
@@ -222,7 +232,7 @@ namespace processor
 		Json::Value value;
 		value["velocity"] = velocity;
 		value["keep_pitch"] = keep_pitch;
-		if (algorithm != Stretch_algorithm::Vocoder) value["algorithm"] = algorithm_name(algorithm);
+		if (algorithm != default_stretch_algorithm()) value["algorithm"] = algorithm_name(algorithm);
 		return value;
 	}
 
@@ -255,7 +265,7 @@ namespace processor
 	{
 		Json::Value value;
 		value["pitch"] = pitch;
-		if (algorithm != Stretch_algorithm::Vocoder) value["algorithm"] = algorithm_name(algorithm);
+		if (algorithm != default_stretch_algorithm()) value["algorithm"] = algorithm_name(algorithm);
 		return value;
 	}
 	void Pitch_modifier::deserialize(const Json::Value& value)

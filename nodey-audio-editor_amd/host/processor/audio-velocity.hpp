@@ -6,18 +6,23 @@
 
 namespace processor
 {
-	// Which GPU implementation stands in for SoundTouch.  The reference's JSON has no such key, so projects saved by
-	// it load as Vocoder (the phase vocoder BASELINE.json's north_star asks for); "algorithm": "soundtouch" selects
-	// the WSOLA + anti-alias FIR + cubic transposer chain restated from SoundTouch 2.3.2 (nae_wsola_*).
+	// Which GPU implementation stands in for SoundTouch: the phase vocoder BASELINE.json's north_star asks for, or the
+	// WSOLA + anti-alias FIR + cubic transposer chain restated from SoundTouch 2.3.2 (nae_wsola_*).
+	// A node's JSON may name it ("algorithm": "vocoder" | "soundtouch").  The reference's JSON has no such key
+	// (audio-velocity.cpp:479-505), so projects saved by it — and freshly created nodes — get the DEFAULT, which the
+	// integrator chooses once at registration: infra::register_all_processors(Stretch_algorithm::Soundtouch) keeps the
+	// reference's audible behaviour for saved projects; the plain call (and this library's own default) is the vocoder.
 	enum class Stretch_algorithm { Vocoder, Soundtouch };
 	const char* algorithm_name(Stretch_algorithm a);
+	Stretch_algorithm default_stretch_algorithm();
+	void set_default_stretch_algorithm(Stretch_algorithm a);
 	Stretch_algorithm algorithm_from_json(const Json::Value& value);
 
 	class Velocity_modifier : public infra::Processor
 	{
 		float velocity = 1;
 		bool keep_pitch = false;
-		Stretch_algorithm algorithm = Stretch_algorithm::Vocoder;
+		Stretch_algorithm algorithm = default_stretch_algorithm();
 
 	  public:
 
@@ -37,7 +42,7 @@ namespace processor
 	class Pitch_modifier : public infra::Processor
 	{
 		float pitch = 0;  // semitones
-		Stretch_algorithm algorithm = Stretch_algorithm::Vocoder;
+		Stretch_algorithm algorithm = default_stretch_algorithm();
 
 	  public:
 

@@ -17,9 +17,13 @@ namespace infra
 		}
 	}
 
-	void register_all_processors()
+	void register_all_processors(processor::Stretch_algorithm default_algorithm)
 	{
 		using namespace processor;
+		set_default_stretch_algorithm(default_algorithm);
 		register_each<Audio_vol, Velocity_modifier, Pitch_modifier, Audio_amix, Audio_bimix, Audio_bimix_v2, Audio_spectrum>();
 	}
+
+	// the reference's signature (src/register.cpp:14, called from App::App): the vocoder is this library's default
+	void register_all_processors() { register_all_processors(processor::Stretch_algorithm::Vocoder); }
 }

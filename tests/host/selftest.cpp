@@ -9,6 +9,7 @@
 #include "processor/audio-vol.hpp"
 #include "../../oracle/nae_oracle.h"
 
+#include "processor/bimix-align.hpp"
 #include <cmath>
 #include <cstring>
 #include <iostream>
@@ -532,11 +533,106 @@ static void test_gpu_bimix_v2()
 	CHECK(lead >= 478 && lead <= 482, "right channel starts ~480 frames late: " << lead);
 }
 
+// velocity_modifier / pitch_modifier nodes without an "algorithm" key (projects saved by the reference) follow the default the
+// integrator picked at registration; an explicit key wins; only a non-default choice is written back
+static void test_default_stretch_algorithm()
+{
+	using namespace processor;
+	Json::Value none, st, voc;
+	st["algorithm"] = "soundtouch";
+	voc["algorithm"] = "vocoder";
+	none["pitch"] = 3.0; st["pitch"] = 3.0; voc["pitch"] = 3.0;
+	CHECK(default_stretch_algorithm() == Stretch_algorithm::Vocoder, "library default is the vocoder");
+	CHECK(algorithm_from_json(none) == Stretch_algorithm::Vocoder && algorithm_from_json(st) == Stretch_algorithm::Soundtouch, "keys under the vocoder default");
+	set_default_stretch_algorithm(Stretch_algorithm::Soundtouch);
+	CHECK(algorithm_from_json(none) == Stretch_algorithm::Soundtouch && algorithm_from_json(voc) == Stretch_algorithm::Vocoder, "keys under the soundtouch default");
+	{
+		Pitch_modifier p;                       // a fresh node takes the default ...
+		p.deserialize(none);
+		CHECK(!p.serialize().isMember("algorithm"), "the default choice is not written back (the reference's JSON stays unchanged)");
+		p.deserialize(voc);                     // ... an explicit choice that differs from it is kept
+		CHECK(p.serialize().isMember("algorithm") && p.serialize()["algorithm"].asString() == "vocoder", "a non-default choice is serialised");
+	}
+	set_default_stretch_algorithm(Stretch_algorithm::Vocoder);
+}
+
+// the pts-alignment rule of Audio_bimix_v2 as a pure function (host/processor/bimix-align.hpp), case by case against
+// /root/reference/src/processor/audio-bimix.cpp:777-872 worked by hand
+static void test_bimix_align_step()
+{
+	using processor::bimix::Span;
+	using processor::bimix::align_step;
+	const int R = 48000;
+	{   // disjoint: the left block ends before the right one begins -> left alone, used up
+		const auto s = align_step(Span{0.0, 480}, Span{0.010, 1000}, R);
+		CHECK(s.first == 0 && s.solo == 480 && s.both == 0 && s.used_up[0] && !s.used_up[1] && s.played[1] == 0, "disjoint spans");
+	}
+	{   // right begins 10 ms into the left block and outlasts it: 480 solo + 520 together; left used up, right loses 520
+		const auto s = align_step(Span{0.0, 1000}, Span{0.010, 1152}, R);
+		CHECK(s.first == 0 && s.solo == 480 && s.both == 520 && s.used_up[0] && !s.used_up[1] && s.played[1] == 520, "overlap, first ends first");
+	}
+	{   // the later block ends first: it is used up, the earlier one loses solo + both
+		const auto s = align_step(Span{0.0, 4000}, Span{0.010, 1000}, R);
+		CHECK(s.first == 0 && s.solo == 480 && s.both == 1000 && !s.used_up[0] && s.used_up[1] && s.played[0] == 1480, "overlap, later ends first");
+	}
+	{   // equal start: the RIGHT side counts as first (the reference tests left < right), nothing solo
+		const auto s = align_step(Span{1.5, 1152}, Span{1.5, 1152}, R);
+		CHECK(s.first == 1 && s.solo == 0 && s.both == 1152 && s.used_up[1] && !s.used_up[0] && s.played[0] == 1152, "simultaneous spans");
+	}
+	{   // right first
+		const auto s = align_step(Span{0.5, 1152}, Span{0.49, 1152}, R);
+		CHECK(s.first == 1 && s.solo == 480 && s.both == 672 && s.used_up[1] && s.played[0] == 672, "right side first");
+	}
+	{   // rounding can ask for one sample more than a block holds: limited by both blocks
+		const auto s = align_step(Span{0.0, 100}, Span{0.0010312, 51}, R);      // 49.4976 samples later -> solo 49, both min(51, 51, 51)
+		CHECK(s.first == 0 && s.solo == 49 && s.both == 51 && s.solo + s.both <= 100, "limits");
+	}
+}
+
+// Audio_bimix (v1) through the runner: left input -> left channel, right input -> right channel, bias (audio-bimix.cpp:83-331,
+// inner loop :310-317), against the oracle's K4
+static void test_gpu_bimix_v1()
+{
+	const int S = 1152 * 5;
+	Runner r;
+	auto l = std::make_shared<Test_source>(), rr = std::make_shared<Test_source>();
+	l->samples = uniform(S * 2, 21);
+	rr->samples = uniform(S * 2, 22);
+	auto mix = std::make_shared<Audio_bimix>();
+	Json::Value v;
+	v["bias"] = 0.25;
+	mix->deserialize(v);
+	auto sink = std::make_shared<Test_sink>();
+	r.add_node(1, l); r.add_node(2, rr); r.add_node(3, mix); r.add_node(4, sink);
+	r.add_link({1, "output", 3, "input_l"});
+	r.add_link({2, "output", 3, "input_r"});
+	r.add_link({3, "output", 4, "input"});
+	const bool ok = r.run();
+	CHECK(ok, "bimix graph runs: " << r.get_processor_resources().at(3)->error_text);
+	if (!ok) return;
+	std::vector<float> ll(S), lr(S), rl(S), rrr(S), oL(S), oR(S);
+	for (int i = 0; i < S; i++) { ll[i] = l->samples[2 * i]; lr[i] = l->samples[2 * i + 1]; rl[i] = rr->samples[2 * i]; rrr[i] = rr->samples[2 * i + 1]; }
+	orc_bimix_f32(ll.data(), lr.data(), rl.data(), rrr.data(), 0.25f, oL.data(), oR.data(), S);
+	size_t pos = 0;
+	bool same = true;
+	for (auto& fr : sink->frames)
+	{
+		const Frame_data* d = fr->data();
+		CHECK(d->format == AV_SAMPLE_FMT_FLTP && d->ch_layout.nb_channels == 2, "bimix delivers planar stereo float");
+		for (int i = 0; i < d->nb_samples && pos < (size_t)S; i++, pos++)
+			same = same && reinterpret_cast<const float*>(d->data[0])[i] == oL[pos] && reinterpret_cast<const float*>(d->data[1])[i] == oR[pos];
+	}
+	CHECK(pos == (size_t)S, "bimix delivered every sample: " << pos);
+	CHECK(same, "bimix output bit-exact vs the oracle (K4)");
+}
+
 int main(int argc, char** argv)
 {
 	const std::string mode = argc > 1 ? argv[1] : "cpu";
 	test_streams_and_scheduler();
 	test_registry_and_json();
+	test_bimix_align_step();
+	test_default_stretch_algorithm();
 	if (mode == "gpu")
 	{
 		test_error_capture();
@@ -546,6 +642,7 @@ int main(int argc, char** argv)
 		test_gpu_pitch_spectrum_fanout();
 		test_gpu_velocity_keep_pitch();
 		test_gpu_pitch_soundtouch_algorithm();
+		test_gpu_bimix_v1();
 		test_gpu_bimix_v2();
 	}
 	std::cout << (failures ? "SELFTEST FAILED " : "SELFTEST OK ") << mode << " failures=" << failures << "\n";

@@ -333,9 +333,35 @@ def test_streaming_handles(ctx, nae):
             frames.append(d_o.download().reshape(k, ch, 513))
             d_o.free()
     assert lib.nae_spectrum_destroy(hs) == 0
-    d_x.free()
     allf = np.concatenate(frames)
-    assert np.array_equal(allf, gpu_spectrum(ctx, nae, x, ch)[0])
+    block = gpu_spectrum(ctx, nae, x, ch)[0]
+    assert np.array_equal(allf, block)
+    # --- partial receives: take FEWER frames than are ready between puts (the handle compacts what is left), then the rest
+    assert lib.nae_spectrum_create(ctx.h, 1024, 256, ch, C.byref(hs)) == 0
+    frames, pos, got = [], 0, C.c_size_t()
+    for n in (5000, 3000, 7000, L):
+        n = min(n, L - pos)
+        assert lib.nae_spectrum_put(hs, d_x.at(pos * ch), n) == 0
+        pos += n
+        k = lib.nae_spectrum_available(hs)
+        take = max(1, k // 3) if k else 0
+        if take:
+            d_o = ctx.empty(take * ch * 513)
+            assert lib.nae_spectrum_receive(hs, d_o.ptr, take, C.byref(got)) == 0 and got.value == take
+            ctx.sync()
+            frames.append(d_o.download().reshape(take, ch, 513))
+            d_o.free()
+            assert lib.nae_spectrum_available(hs) == k - take
+    while lib.nae_spectrum_available(hs):
+        k = min(7, lib.nae_spectrum_available(hs))
+        d_o = ctx.empty(k * ch * 513)
+        assert lib.nae_spectrum_receive(hs, d_o.ptr, k, C.byref(got)) == 0 and got.value == k
+        ctx.sync()
+        frames.append(d_o.download().reshape(k, ch, 513))
+        d_o.free()
+    assert lib.nae_spectrum_destroy(hs) == 0
+    d_x.free()
+    assert np.array_equal(np.concatenate(frames), block)
 
 
 def test_k7_k8_odd_layouts_equal_clean_layouts(ctx, nae):

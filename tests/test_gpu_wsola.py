@@ -117,7 +117,7 @@ def test_edge_inputs(ctx, nae):
     assert np.array_equal(y[0].view(np.uint32), ref.view(np.uint32))
 
 
-def stream_wsola(ctx, x, ch, sr, rate, pitch, put_sizes, recv_chunk=3456, device_put=False):
+def stream_wsola(ctx, x, ch, sr, rate, pitch, put_sizes, recv_chunk=3456, device_put=False, pinned=None):
     """drive the handle the way audio-velocity.cpp:344-440 drives SoundTouch: put a frame, drain what is ready"""
     lib = ctx.lib
     L = x.size // ch
@@ -138,6 +138,12 @@ def stream_wsola(ctx, x, ch, sr, rate, pitch, put_sizes, recv_chunk=3456, device
         i += 1
         if device_put:
             assert lib.nae_wsola_put(h, d_x.at(pos * ch), n) == 0
+        elif pinned is not None:
+            # ONE page-locked staging buffer, overwritten for every put: legal because put_host returns only when the
+            # copy has left the buffer (with pinned memory hipMemcpyAsync is truly asynchronous)
+            pinned[: n * ch] = x[pos * ch:(pos + n) * ch]
+            assert lib.nae_wsola_put_host(h, pinned.ctypes.data, n) == 0
+            pinned[: n * ch] = np.nan
         else:
             chunk = np.ascontiguousarray(x[pos * ch:(pos + n) * ch])
             assert lib.nae_wsola_put_host(h, chunk.ctypes.data, n) == 0
@@ -166,6 +172,41 @@ def test_streaming_handle_equals_oracle_stream(ctx, nae, ch, rate, pitch):
         assert np.array_equal(y.view(np.uint32), ref.view(np.uint32)), (sizes, int(np.count_nonzero(y != ref)))
         if sizes == [1152]:
             assert early > 0
+
+
+def test_put_host_from_one_reused_pinned_buffer(ctx, nae):
+    """the caller's buffer is free again when nae_wsola_put_host / nae_stretch_put_host return: feeding every chunk through
+    the same page-locked buffer (and trashing it right after each put) gives the oracle's stream"""
+    sr, ch, L, p = 48000, 2, 60000, 2 ** (3 / 12)
+    x = orc.fill_uniform(L * ch, 78)
+    pinned = ctx.pinned(4096 * ch)
+    y, _ = stream_wsola(ctx, x, ch, sr, 1.0, p, [1152, 4096, 37], pinned=pinned)
+    ref = orc.st_process(x, ch, sr, 1.0, p, chunk=[1152, 4096, 37])
+    assert np.array_equal(y.view(np.uint32), ref.view(np.uint32))
+    # the phase-vocoder handle
+    lib = ctx.lib
+    h = C.c_void_p()
+    pf = float(np.float32(p))
+    assert lib.nae_stretch_create(ctx.h, sr, ch, 1.0, pf, C.byref(h)) == 0
+    outs, pos = [], 0
+    while pos < L:
+        n = min(4096, L - pos)
+        pinned[: n * ch] = x[pos * ch:(pos + n) * ch]
+        assert lib.nae_stretch_put_host(h, pinned.ctypes.data, n) == 0
+        pinned[: n * ch] = np.nan
+        pos += n
+    assert lib.nae_stretch_flush(h) == 0
+    k = lib.nae_stretch_available(h)
+    buf, got = np.empty(k * ch, np.float32), C.c_size_t()
+    assert lib.nae_stretch_receive_host(h, buf.ctypes.data, k, C.byref(got)) == 0 and got.value == k
+    assert lib.nae_stretch_destroy(h) == 0
+    ctx.free_pinned(pinned)
+    d_x = ctx.array(x)
+    pl = ctx.stretch_plan(1.0, pf, L)
+    d_y = ctx.empty(pl.out_len * ch)
+    ctx.stretch_block(1.0, pf, nae.Sig.interleaved(d_x.ptr, L, ch), L, ch, 1, nae.Sig.interleaved(d_y.ptr, pl.out_len, ch))
+    assert np.array_equal(buf.view(np.uint32), d_y.download().view(np.uint32))
+    d_x.free(); d_y.free()
 
 
 def test_create_rejects_what_the_reference_rejects(ctx, nae):
