@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--semitones", type=float, default=SEMITONES, help="pitch node setting (headline: +3)")
     ap.add_argument("--rate", type=float, default=1.0, help="SoundTouch setRate of the pitch node (headline: 1)")
     ap.add_argument("--no-alt", action="store_true", help="skip the side measurement of the SoundTouch-shaped pitch node")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the host-buffers-on-both-sides measurement (pcie_inclusive)")
     return ap.parse_args()
 
 
@@ -264,6 +265,13 @@ def main():
             "graph_sample_frames_per_s": n_streams * S / ((w_ms + other) * 1e-3)}
         ctx.graph4(g)                                        # restore the vocoder result for the parity check below
         ctx.sync()
+
+    # ---- the same graph with HOST buffers on both sides of the boundary (pinned staging, two streams in ping-pong): what an
+    # editor process behind the plugin API would see.  Reported beside the headline, never part of `value`.
+    if not a.no_pcie and world == 1:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_pcie
+        out["pcie_inclusive"] = bench_pcie.measure(nae, device=local_rank, streams=512, chunk=64, S=S, semitones=a.semitones)
 
     # ---- CPU baseline (reported, not the target): the oracle's restatement of the same graph, 1 thread
     if not a.no_cpu_baseline and world == 1:

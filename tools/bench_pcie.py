@@ -1,8 +1,14 @@
 #!/usr/bin/env python3
-"""End-to-end rate of the C5 graph when the boundary hands over HOST buffers (what the per-frame adapter does):
-H2D of the inputs + graph + D2H of the pitch and spectrum outputs, pageable numpy memory through nae_memcpy_*.
-Never the headline `value` (bench.py times HBM-resident data); reported in DESIGN.md §9.
-   python tools/bench_pcie.py [--streams 256]"""
+"""Rate of the C5 graph when the boundary hands over HOST buffers (what the per-frame adapter does): H2D of the inputs, the
+graph, D2H of the pitch and spectrum outputs.  Never the headline `value` (bench.py times HBM-resident data); bench.py
+reports it as `pcie_inclusive`.
+
+Pipeline: page-locked staging (nae_malloc_host) and three contexts — three streams — taking turns, so the upload of chunk i+1,
+the kernels of chunk i and the download of chunk i-1 overlap (uploads and downloads use different DMA engines).  Per
+sample-frame 8 B go up and 24.03 B come down; the downlink is the bound: 63 GB/s (PCIe Gen5 x16) / 24.03 B = 2.6e9
+sample-frames/s at best.
+
+    python tools/bench_pcie.py [--streams 512] [--chunk 64]"""
 import argparse
 import json
 import os
@@ -12,50 +18,91 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
-import naeload
-
-ap = argparse.ArgumentParser()
-ap.add_argument("--streams", type=int, default=256)
-ap.add_argument("--reps", type=int, default=3)
-a = ap.parse_args()
-nae = naeload.load()
-ctx = nae.Context(0)
-n, S, p = a.streams, 480000, 2 ** (3 / 12)
-pl = ctx.stretch_plan(1.0, p, S)
-F = ctx.spectrum_frames(pl.out_len)
-h_a = np.random.default_rng(1).uniform(-1, 1, n * S * 2).astype(np.float32)
-h_b = np.random.default_rng(2).uniform(-1, 1, S * 2).astype(np.float32)
-h_pitch = np.empty(n * pl.out_len * 2, np.float32)
-h_spec = np.empty(n * F * 2 * 513, np.float32)
-d_a, d_b = ctx.empty(n * S * 2), ctx.empty(S * 2)
-d_mix, d_pitch, d_spec = ctx.empty(n * S * 2), ctx.empty(n * pl.out_len * 2), ctx.empty(n * F * 2 * 513)
-g = nae.Graph4()
-g.in_a = nae.Sig.interleaved(d_a.ptr, S, 2)
-g.in_b = nae.Sig.interleaved(d_b.ptr, S, 2, shared=True)
-g.vol_a = g.vol_b = 0.5
-g.mix_out = nae.Sig.planar(d_mix.ptr, S, 2)
-g.rate, g.pitch = 1.0, p
-g.pitch_out = nae.Sig.interleaved(d_pitch.ptr, pl.out_len, 2)
-g.spec_out, g.spec_stream_stride = d_spec.ptr, F * 2 * 513
-g.S, g.n_streams = S, n
 
 
-def once():
+class Lane:
+    """one context with its device buffers and pinned staging for `chunk` streams"""
+
+    def __init__(self, nae, device, chunk, S, p, h_b):
+        self.nae, self.chunk, self.S = nae, chunk, S
+        self.ctx = ctx = nae.Context(device)
+        self.pl = pl = ctx.stretch_plan(1.0, p, S)
+        self.F = F = ctx.spectrum_frames(pl.out_len)
+        self.h_in = ctx.pinned(chunk * S * 2)
+        self.h_pitch = ctx.pinned(chunk * pl.out_len * 2)
+        self.h_spec = ctx.pinned(chunk * F * 2 * 513)
+        self.d_a, self.d_b = ctx.empty(chunk * S * 2), ctx.array(h_b)
+        self.d_mix, self.d_pitch, self.d_spec = ctx.empty(chunk * S * 2), ctx.empty(chunk * pl.out_len * 2), ctx.empty(chunk * F * 2 * 513)
+        g = self.g = nae.Graph4()
+        g.in_a = nae.Sig.interleaved(self.d_a.ptr, S, 2)
+        g.in_b = nae.Sig.interleaved(self.d_b.ptr, S, 2, shared=True)
+        g.vol_a = g.vol_b = 0.5
+        g.mix_out = nae.Sig.planar(self.d_mix.ptr, S, 2)
+        g.rate, g.pitch = 1.0, p
+        g.pitch_out = nae.Sig.interleaved(self.d_pitch.ptr, pl.out_len, 2)
+        g.spec_out, g.spec_stream_stride = self.d_spec.ptr, F * 2 * 513
+        g.S, g.n_streams = S, chunk
+
+    def enqueue(self):
+        """upload, graph, download — all asynchronous on this lane's stream"""
+        c = self.ctx
+        c._ck(c.lib.nae_memcpy_h2d(c.h, self.d_a.ptr, self.h_in.ctypes.data, self.h_in.nbytes))
+        c.graph4(self.g)
+        c._ck(c.lib.nae_memcpy_d2h(c.h, self.h_pitch.ctypes.data, self.d_pitch.ptr, self.h_pitch.nbytes))
+        c._ck(c.lib.nae_memcpy_d2h(c.h, self.h_spec.ctypes.data, self.d_spec.ptr, self.h_spec.nbytes))
+
+    def close(self):
+        for a in (self.h_in, self.h_pitch, self.h_spec):
+            self.ctx.free_pinned(a)
+        self.ctx.close()
+
+
+def measure(nae, device=0, streams=512, chunk=64, S=480000, semitones=3.0, lanes=3):
+    p = 2.0 ** (semitones / 12.0)
+    h_b = np.random.default_rng(2).uniform(-1, 1, S * 2).astype(np.float32)
+    L = [Lane(nae, device, chunk, S, p, h_b) for _ in range(lanes)]
+    src = np.random.default_rng(1).uniform(-1, 1, chunk * S * 2).astype(np.float32)
+    for ln in L:
+        ln.h_in[:] = src                                   # (a real caller fills the staging buffer while the lane is busy)
+        ln.enqueue()
+    for ln in L:
+        ln.ctx.sync()
+    n_chunks = max(lanes, streams // chunk)
+    t0 = time.perf_counter()
+    for i in range(n_chunks):
+        ln = L[i % lanes]
+        ln.ctx.sync()                                       # its previous chunk has left the staging buffers
+        ln.enqueue()
+    for ln in L:
+        ln.ctx.sync()
+    dt = time.perf_counter() - t0
+    # serial reference on one lane: the three phases one after the other
+    ln = L[0]
+    c = ln.ctx
     t = [time.perf_counter()]
-    ctx._ck(ctx.lib.nae_memcpy_h2d(ctx.h, d_a.ptr, h_a.ctypes.data, h_a.nbytes))
-    ctx._ck(ctx.lib.nae_memcpy_h2d(ctx.h, d_b.ptr, h_b.ctypes.data, h_b.nbytes))
-    ctx.sync(); t.append(time.perf_counter())
-    ctx.graph4(g)
-    ctx.sync(); t.append(time.perf_counter())
-    ctx._ck(ctx.lib.nae_memcpy_d2h(ctx.h, h_pitch.ctypes.data, d_pitch.ptr, h_pitch.nbytes))
-    ctx._ck(ctx.lib.nae_memcpy_d2h(ctx.h, h_spec.ctypes.data, d_spec.ptr, h_spec.nbytes))
-    ctx.sync(); t.append(time.perf_counter())
-    return [t[i + 1] - t[i] for i in range(3)]
+    c._ck(c.lib.nae_memcpy_h2d(c.h, ln.d_a.ptr, ln.h_in.ctypes.data, ln.h_in.nbytes)); c.sync(); t.append(time.perf_counter())
+    c.graph4(ln.g); c.sync(); t.append(time.perf_counter())
+    c._ck(c.lib.nae_memcpy_d2h(c.h, ln.h_pitch.ctypes.data, ln.d_pitch.ptr, ln.h_pitch.nbytes))
+    c._ck(c.lib.nae_memcpy_d2h(c.h, ln.h_spec.ctypes.data, ln.d_spec.ptr, ln.h_spec.nbytes)); c.sync(); t.append(time.perf_counter())
+    up, down = ln.h_in.nbytes, ln.h_pitch.nbytes + ln.h_spec.nbytes
+    out = {"value": n_chunks * chunk * S / dt, "unit": "sample-frames/s", "streams": n_chunks * chunk, "chunk_streams": chunk, "lanes": lanes,
+           "staging": "page-locked (hipHostMalloc)", "seconds": round(dt, 4),
+           "bytes_per_sample_frame": {"up": up / (chunk * S), "down": down / (chunk * S)},
+           "down_GBps_in_pipeline": n_chunks * down / dt / 1e9, "up_GBps_in_pipeline": n_chunks * up / dt / 1e9,
+           "one_chunk_serial": {"h2d_ms": (t[1] - t[0]) * 1e3, "graph_ms": (t[2] - t[1]) * 1e3, "d2h_ms": (t[3] - t[2]) * 1e3,
+                                "h2d_GBps": up / (t[1] - t[0]) / 1e9, "d2h_GBps": down / (t[3] - t[2]) / 1e9,
+                                "sample_frames_per_s": chunk * S / (t[3] - t[0])},
+           "bound": "downlink: 24.03 B per sample-frame over PCIe Gen5 x16 (63 GB/s spec) = 2.6e9 sample-frames/s"}
+    for ln in L:
+        ln.close()
+    return out
 
 
-once()
-best = min((once() for _ in range(a.reps)), key=sum)
-tot = sum(best)
-print(json.dumps({"streams": n, "sample_frames": n * S, "h2d_s": best[0], "graph_s": best[1], "d2h_s": best[2],
-                  "h2d_GBps": (h_a.nbytes + h_b.nbytes) / best[0] / 1e9, "d2h_GBps": (h_pitch.nbytes + h_spec.nbytes) / best[2] / 1e9,
-                  "sample_frames_per_s_incl_pcie": n * S / tot, "sample_frames_per_s_graph_only": n * S / best[1]}))
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--streams", type=int, default=512)
+    ap.add_argument("--chunk", type=int, default=64)
+    ap.add_argument("--lanes", type=int, default=3)
+    a = ap.parse_args()
+    import naeload
+    print(json.dumps(measure(naeload.load(), streams=a.streams, chunk=a.chunk, lanes=a.lanes)))
