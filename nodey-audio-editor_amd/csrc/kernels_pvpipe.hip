@@ -120,7 +120,6 @@ __global__ __launch_bounds__(kPipeThreads, 6) void pv_pipe_kernel(SigViewD src, 
                     const cf w = lds_ld(hw + 64 * j);
                     va[j] = cf{nxt[j].x * w.x, nxt[j].y * w.y};
                 }
-                if (t + 1 < n) load_frame_raw<kUnit>(nxt, in, frame_start(p, f_first + t + 1), lane);
                 fft512_pad_a(va, L);
             }
             PIPE_BARRIER(t, 1);                               // B: R2 holds X of frame t-1 in registers
@@ -129,6 +128,8 @@ __global__ __launch_bounds__(kPipeThreads, 6) void pv_pipe_kernel(SigViewD src, 
 #pragma unroll
                 for (int r = 0; r < 8; r++) lds_st(L.nat + 64 * r, va[r]);
                 if (lane == 0) S1[512] = va[0];               // so that the mirror of bin 0 is read like any other
+                // request the next frame now: R1 is the shortest role, the loads land while it waits at the barriers
+                if (t + 1 < n) load_frame_raw<kUnit>(nxt, in, frame_start(p, f_first + t + 1), lane);
             }
         }
 #ifdef NAE_PIPE_STAMPS

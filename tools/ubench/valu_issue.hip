@@ -21,7 +21,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct Stamp { unsigned long long cyc, real; unsigned hw_id, xcc_id; };
 
-enum Op { FMA, MUL, ADD, SIN, RCP, SQRT, CVT_I32, MUL_LO_U32, MAD_U64_U32, MAD_I64_I32, AND_B32, CNDMASK, PK_FMA, FMA_DEP, FMA_SIN_9_1, DS_READ_B64, DS_WRITE_B64, DS_READ2_B64, DS_READ2ST64_B64, DS_WRITE2_B64, DS_WRITE2ST64_B64, DS_READ_B128, DS_WRITE_B128, MUL_SGPR, MUL_LIT, CMP_CNDMASK, CNDMASK_S64, MAX_F32, MOV_B32, FMAC_F32, FMAAK_F32, DIV_SCALE, DIV_FMAS, DIV_FIXUP, ADD_2SRC, FMA_3SRC, ADD_2SRC_LONG, FMA_3SRC_LONG, FMAC_LONG, MIX_FFT, ADD15_DSW1, ADD15_DSR1, ADD14_DSW1_DSR1, ADD15_GLD1, ADD15_GST1, N_OPS };
+enum Op { FMA, MUL, ADD, SIN, RCP, SQRT, CVT_I32, MUL_LO_U32, MAD_U64_U32, MAD_I64_I32, AND_B32, CNDMASK, PK_FMA, FMA_DEP, FMA_SIN_9_1, DS_READ_B64, DS_WRITE_B64, DS_READ2_B64, DS_READ2ST64_B64, DS_WRITE2_B64, DS_WRITE2ST64_B64, DS_READ_B128, DS_WRITE_B128, MUL_SGPR, MUL_LIT, CMP_CNDMASK, CNDMASK_S64, MAX_F32, MOV_B32, FMAC_F32, FMAAK_F32, DIV_SCALE, DIV_FMAS, DIV_FIXUP, ADD_2SRC, FMA_3SRC, ADD_2SRC_LONG, FMA_3SRC_LONG, FMAC_LONG, MIX_FFT, ADD15_DSW1, ADD15_DSR1, ADD14_DSW1_DSR1, ADD15_GLD1, ADD15_GST1, ADD_DPP_QUAD, ADD_DPP_ROR8, MOV_DPP_ROR8_BANK, PERMLANE32_SWAP, PERMLANE16_SWAP, N_OPS };
 static const char* kOpName[N_OPS] = {"v_fma_f32", "v_mul_f32", "v_add_f32", "v_sin_f32", "v_rcp_f32", "v_sqrt_f32", "v_cvt_i32_f32", "v_mul_lo_u32",
                                      "v_mad_u64_u32", "v_mad_i64_i32", "v_and_b32", "v_cndmask_b32", "v_pk_fma_f32 (2 lanes-ops each)",
                                      "v_fma_f32, ONE dependent chain", "15 v_fma_f32 : 1 v_sin_f32", "ds_read_b64 (no wait inside)", "ds_write_b64 (no wait inside)",
@@ -34,7 +34,9 @@ static const char* kOpName[N_OPS] = {"v_fma_f32", "v_mul_f32", "v_add_f32", "v_s
                                      "same v_add_f32 stream, 4096-instruction loop body (16 KiB of code)", "same v_fma_f32 stream, 4096-instruction loop body (32 KiB)",
                                      "v_fmac_f32 d += s0*s1 (VOP2), rotating, 4096-instruction body", "add/sub/mul/fma mix of a radix-8 butterfly, rotating registers",
                                      "15 v_add_f32 : 1 ds_write_b64 (per 16 instructions)", "15 v_add_f32 : 1 ds_read_b64", "14 v_add_f32 : 1 ds_write_b64 : 1 ds_read_b64",
-                                     "15 v_add_f32 : 1 global_load_dwordx2 (L2-resident, 512 B per wave)", "15 v_add_f32 : 1 global_store_dwordx2"};
+                                     "15 v_add_f32 : 1 global_load_dwordx2 (L2-resident, 512 B per wave)", "15 v_add_f32 : 1 global_store_dwordx2",
+                                     "v_add_f32_dpp quad_perm:[1,0,3,2] (rotating registers)", "v_add_f32_dpp row_ror:8", "v_mov_b32_dpp row_ror:8 bank_mask:0x3",
+                                     "v_permlane32_swap_b32", "v_permlane16_swap_b32"};
 
 template <int OP>
 __device__ __forceinline__ void block16(float (&a)[16], float2 (&p)[8], unsigned long long (&w)[8], f32x4 (&q4)[4], float b, float c, unsigned lds_addr,
@@ -96,6 +98,11 @@ __device__ __forceinline__ void block16(float (&a)[16], float2 (&p)[8], unsigned
             else if (w_slot && OP == ADD15_GST1) asm volatile("global_store_dwordx2 %0, %1, %2" :: "v"(lds_addr16 & 0x3f8u), "v"(p[3]), "s"(gptr));
             else asm volatile("v_add_f32 %0, %1, %2" : "=v"(a[i]) : "v"(a[(i + 5) & 15]), "v"(a[(i + 10) & 15]));
         }
+        if (OP == ADD_DPP_QUAD) asm volatile("v_add_f32_dpp %0, %1, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(a[i]) : "v"(a[(i + 5) & 15]), "v"(a[(i + 10) & 15]));
+        if (OP == ADD_DPP_ROR8) asm volatile("v_add_f32_dpp %0, %1, %2 row_ror:8 row_mask:0xf bank_mask:0xf" : "=v"(a[i]) : "v"(a[(i + 5) & 15]), "v"(a[(i + 10) & 15]));
+        if (OP == MOV_DPP_ROR8_BANK) asm volatile("v_mov_b32_dpp %0, %1 row_ror:8 row_mask:0xf bank_mask:0x3" : "+v"(a[i]) : "v"(a[(i + 5) & 15]));
+        if (OP == PERMLANE32_SWAP) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a[i]), "+v"(a[(i + 8) & 15]));
+        if (OP == PERMLANE16_SWAP) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(a[i]), "+v"(a[(i + 8) & 15]));
         if (OP == DS_READ_B128) asm volatile("ds_read_b128 %0, %1" : "=v"(q4[i & 3]) : "v"(lds_addr16));
         if (OP == DS_WRITE_B128) asm volatile("ds_write_b128 %0, %1" :: "v"(lds_addr16), "v"(q4[i & 3]));
     }
@@ -197,6 +204,7 @@ int main(int argc, char** argv)
                 CASE(MAX_F32) CASE(MOV_B32) CASE(FMAC_F32) CASE(FMAAK_F32) CASE(DIV_SCALE) CASE(DIV_FMAS) CASE(DIV_FIXUP)
                 CASE(ADD_2SRC) CASE(FMA_3SRC) CASE(ADD_2SRC_LONG) CASE(FMA_3SRC_LONG) CASE(FMAC_LONG) CASE(MIX_FFT)
                 CASE(ADD15_DSW1) CASE(ADD15_DSR1) CASE(ADD14_DSW1_DSR1) CASE(ADD15_GLD1) CASE(ADD15_GST1)
+                CASE(ADD_DPP_QUAD) CASE(ADD_DPP_ROR8) CASE(MOV_DPP_ROR8_BANK) CASE(PERMLANE32_SWAP) CASE(PERMLANE16_SWAP)
 #undef CASE
             }
             std::vector<double> cpi, ghz;
