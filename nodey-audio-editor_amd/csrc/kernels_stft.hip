@@ -71,67 +71,116 @@ __global__ __launch_bounds__(kThreads, 4) void spectrum_kernel(SigViewD src, lon
     }
 }
 
-// interleaved-stereo fast path: one 16-byte load per lane fetches (L0 R0 L1 R1), so the frame is read once for both
+// interleaved-stereo fast path: one 16-byte load per lane and row fetches (L0 R0 L1 R1), so a frame is read once for both
 // channels and the window is applied once; requires a 16-byte aligned stream base and an even stream stride.
-// A wave walks kSpecChunk consecutive frames of one stream, so the table fill and the twiddle loads of the
-// workgroup are amortised over 8 x kSpecChunk frames.
+// A wave walks kSpecChunk consecutive frames of one stream (the 75 % overlap of consecutive frames is re-read through
+// L1 / L2); both channels run FFT -> r2c split -> magnitude on the padded low-register FFT (stft_device.h).
+// Loop order:  window(f) -> stores(f-1) -> loads(f+1) -> FFT / split / magnitudes of frame f.  Vector-memory operations of a
+// wave retire in issue order and share one counter, so a load issued behind its own frame's 18 stores can only be waited
+// for together with them — and a store takes microseconds to be acknowledged.  Here the wait in front of window(f) covers
+// the loads of frame f and, older than them, only the stores of frame f-2.  The magnitudes of the previous frame ride along
+// in 18 registers.  (tools/ubench/spec_abl.hip, profiles/r02_spectrum_ablation.md: 3.43 -> 3.16 ms on the C5 signal; stores
+// that bypass L2 allocation — they are never read again by this kernel — another 0.1-0.3 ms.)
 constexpr int kSpecChunk = 32;
-// Consecutive frames overlap by 768 of 1024 sample-frames = 6 of the 8 register rows of the FFT input layout
-// (pair index n = lane + 64 j, hop = 128 pairs = 2 rows), so the raw samples are kept in registers and each new
-// frame loads only its last 2 rows: HBM/L2 read traffic drops from ~3.4x to ~1.1x of the input.
-__global__ __launch_bounds__(kThreads, 4) void spectrum_stereo_kernel(const float* __restrict__ src, long long src_ss, long long T,
-                                                                     long long n_frames, long long chunks_per_stream,
-                                                                     long long n_items, float* __restrict__ dst,
-                                                                     long long dst_ss, Tables tb)
+#ifndef NAE_SPEC_STORE_AUX
+#define NAE_SPEC_STORE_AUX 2
+#endif
+constexpr int kSpecStoreAux = NAE_SPEC_STORE_AUX;       // cache policy bits of the spectrum stores (2 = nt)
+constexpr size_t kLdsTablesPad = NAE_FFT_N * sizeof(float) + (kT1024Pad + 64 + kTwaCf) * sizeof(cf);
+constexpr size_t kLdsSpecStereo = kLdsTablesPad + kWaves * kPadScratchCf * sizeof(cf);
+
+__global__ __launch_bounds__(kThreads, 4) void spectrum_stereo_kernel(const float* __restrict__ src, long long src_ss, long long n_frames,
+                                                                     long long chunks_per_stream, long long n_items,
+                                                                     float* __restrict__ dst, long long dst_ss, Tables tb)
 {
-    LdsLayout L = lds_setup(tb);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* hann = reinterpret_cast<float*>(smem);
+    cf* t1024 = reinterpret_cast<cf*>(smem + NAE_FFT_N * sizeof(float));
+    cf* w64 = t1024 + kT1024Pad;
+    cf* twa = w64 + 64;
+    for (int i = threadIdx.x; i < NAE_FFT_N; i += kThreads) hann[i] = tb.hann[i];
+    for (int i = threadIdx.x; i < NAE_FFT_BINS; i += kThreads) t1024[i] = tb.t1024[i];
+    if (threadIdx.x < 64) w64[threadIdx.x] = tb.w512[8 * (threadIdx.x >> 3) * (threadIdx.x & 7)];
+    fill_twa(twa, tb.w512, threadIdx.x, kThreads);
+    __syncthreads();
     const int lane = threadIdx.x & 63;
     const long long item = (long long)blockIdx.x * kWaves + wave_id();
     if (item >= n_items) return;
-    const long long s = item / chunks_per_stream;
-    const long long f0 = (item % chunks_per_stream) * kSpecChunk;
-    long long f1 = f0 + kSpecChunk;
-    if (f1 > n_frames) f1 = n_frames;
-    FftTw tw;
-    load_fft_tw(tw, tb.w512, L.w64, lane);
-    const float* sbase = src + s * src_ss + 4 * lane;              // frames lie fully inside [0, T) by construction
+    cf* scratch = reinterpret_cast<cf*>(smem + kLdsTablesPad) + wave_id() * kPadScratchCf;
+    const FftLds L = make_fft_lds(scratch, twa, w64, lane);
+    const cf* hw = reinterpret_cast<const cf*>(hann) + lane;
+    const cf* tsp = t1024 + lane;
+    // (the 64-bit divisions run on the vector ALU: bring the wave-uniform results back to scalar registers)
+    const int s = __builtin_amdgcn_readfirstlane((int)(item / chunks_per_stream));
+    const int f0 = __builtin_amdgcn_readfirstlane((int)(item % chunks_per_stream)) * kSpecChunk;
+    const int f1 = f0 + kSpecChunk > (int)n_frames ? (int)n_frames : f0 + kSpecChunk;
+    const float* sbase = src + (long long)s * src_ss + 4 * lane;   // frames lie fully inside [0, T) by construction
+    float* obase = dst + (long long)s * dst_ss;
+    float ma[9], mb[9];
+    auto store_frame = [&](int fs) {
+        // buffer stores: scalar descriptor of the frame's two spectra + one lane offset (no 64-bit per-lane addresses)
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(obase + ((long long)fs * 2) * NAE_FFT_BINS, 0, -1, 0x00020000);
+#pragma unroll
+        for (int r = 0; r < 8; r++) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ma[r]), rs, 4 * lane, 256 * r, kSpecStoreAux);
+        if (lane == 0) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ma[8]), rs, 2048, 0, kSpecStoreAux);
+#pragma unroll
+        for (int r = 0; r < 8; r++) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mb[r]), rs, 4 * lane, NAE_FFT_BINS * 4 + 256 * r, kSpecStoreAux);
+        if (lane == 0) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mb[8]), rs, 2048, NAE_FFT_BINS * 4, kSpecStoreAux);
+    };
+    // one channel: FFT, r2c split delivering 2 X (no 1/2 factors: |2 X|^2 = 4 |X|^2 and sqrt(4 a) = 2 sqrt(a) are exact
+    // scalings, so 0.5 * sqrt(.) is the canonical magnitude bit for bit, for |X| above ~1e-18), magnitudes
+    auto channel = [&](cf (&v)[8], float (&mc)[9]) {
+        fft512_pad(v, L);
+#pragma unroll
+        for (int r = 0; r < 8; r++) lds_st(L.nat + 64 * r, v[r]);
+        if (lane == 0) scratch[512] = v[0];
+        wave_lds_sync();
+        const cf z0 = scratch[0];
+        {
+            const cf E = cf{z0.x + z0.x, z0.y - z0.y};
+            const cf O = cf{z0.x - z0.x, z0.y + z0.y};
+            const cf P = cmul_tw(O, t1024[512]);
+            const cf nyq = cf{E.x + P.y, E.y - P.x};
+            mc[8] = 0.5f * sqrt_rn(nyq.x * nyq.x + nyq.y * nyq.y);
+        }
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const cf A = v[r], B = lds_ld(L.mir + 448 - 64 * r);
+            const cf E = cf{A.x + B.x, A.y - B.y};
+            const cf O = cf{A.x - B.x, A.y + B.y};
+            const cf P = cmul_tw(O, lds_ld(tsp + 64 * r));
+            const cf X = cf{E.x + P.y, E.y - P.x};
+            mc[r] = 0.5f * sqrt_rn(X.x * X.x + X.y * X.y);
+        }
+        wave_lds_sync();
+    };
     float4 raw[8];
-    {
-        const float* base = sbase + 2 * (f0 * NAE_HOP);
+    if (f0 < f1) {
+        const float* base = sbase + 2 * ((long long)f0 * NAE_HOP);
 #pragma unroll
-        for (int j = 0; j < 6; j++) raw[j + 2] = *reinterpret_cast<const float4*>(base + 256 * j);   // rows 0..5 of frame f0, pre-shifted
+        for (int j = 0; j < 8; j++) raw[j] = *reinterpret_cast<const float4*>(base + 256 * j);
     }
-    cf v0[8], v1[8];
 #pragma unroll 1
-    for (long long f = f0; f < f1; f++) {
-        const float* base = sbase + 2 * (f * NAE_HOP);
-#pragma unroll
-        for (int j = 0; j < 6; j++) raw[j] = raw[j + 2];
-        raw[6] = *reinterpret_cast<const float4*>(base + 256 * 6);
-        raw[7] = *reinterpret_cast<const float4*>(base + 256 * 7);
+    for (int f = f0; f < f1; f++) {
+        cf v0[8], v1[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            const float2 w = *reinterpret_cast<const float2*>(L.hann + 2 * (lane + 64 * j));
+            const cf w = lds_ld(hw + 64 * j);
             v0[j] = cf{raw[j].x * w.x, raw[j].z * w.y};
             v1[j] = cf{raw[j].y * w.x, raw[j].w * w.y};
         }
-        float* o = dst + s * dst_ss + (f * 2) * NAE_FFT_BINS;
-#pragma unroll 1
-        for (int c = 0; c < 2; c++) {
-            if (c == 1) {
+        if (f > f0) store_frame(f - 1);
+        if (f + 1 < f1) {
+            const float* base = sbase + 2 * ((long long)(f + 1) * NAE_HOP);
 #pragma unroll
-                for (int j = 0; j < 8; j++) v0[j] = v1[j];
-            }
-            fft512_fwd<1>(v0, L.scratch, tw, lane);
-            // 2 X from the split; |2 X|^2 = 4 |X|^2 and sqrt(4 a) = 2 sqrt(a) are exact scalings, so 0.5 * sqrt(.) is
-            // the canonical magnitude bit for bit (for |X| above ~1e-18, where no square is denormal)
-            const cf nyq = rfft_split<true>(v0, L.scratch, L.t1024, lane);
-#pragma unroll
-            for (int r = 0; r < 8; r++) o[lane + 64 * r] = 0.5f * sqrt_rn(v0[r].x * v0[r].x + v0[r].y * v0[r].y);
-            if (lane == 0) o[512] = 0.5f * sqrt_rn(nyq.x * nyq.x + nyq.y * nyq.y);
-            o += NAE_FFT_BINS;
+            for (int j = 0; j < 8; j++) raw[j] = *reinterpret_cast<const float4*>(base + 256 * j);
         }
+        channel(v0, ma);
+        __builtin_amdgcn_sched_barrier(0);      // keep the two channels apart: interleaved, their live values exceed the register budget
+        channel(v1, mb);
+        __builtin_amdgcn_sched_barrier(0);
     }
+    if (f1 > f0) store_frame(f1 - 1);
 }
 
 // ------------------------------------------------------------------------------------------------ K7
@@ -568,7 +617,7 @@ int nae_launch_spectrum(nae_ctx* ctx, const nae_sig* src, size_t T, int ch, size
         const long long chunks = ((long long)F + kSpecChunk - 1) / kSpecChunk;
         const long long citems = chunks * (long long)n_streams;
         NAE_KLAUNCH(ctx, "spectrum_kernel", spectrum_stereo_kernel, dim3((unsigned)((citems + kWaves - 1) / kWaves)), dim3(kThreads),
-                    lds, ctx->stream, static_cast<const float*>(src->base), (long long)src->stream_stride, (long long)T,
+                    kLdsSpecStereo, ctx->stream, static_cast<const float*>(src->base), (long long)src->stream_stride,
                     (long long)F, chunks, citems, dst, (long long)dst_stream_stride, tb);
     }
     else if (src->frame_stride == 1)
