@@ -73,15 +73,17 @@ __global__ __launch_bounds__(kThreads, 4) void spectrum_kernel(SigViewD src, lon
 
 // interleaved-stereo fast path: one 16-byte load per lane and row fetches (L0 R0 L1 R1), so a frame is read once for both
 // channels and the window is applied once; requires a 16-byte aligned stream base and an even stream stride.
-// A wave walks kSpecChunk consecutive frames of one stream (the 75 % overlap of consecutive frames is re-read through
-// L1 / L2); both channels run FFT -> r2c split -> magnitude on the padded low-register FFT (stft_device.h).
+// A wave walks kSpecChunk consecutive frames of one stream; both channels run FFT -> r2c split -> magnitude on the padded low-register FFT (stft_device.h).
 // Loop order:  window(f) -> stores(f-1) -> loads(f+1) -> FFT / split / magnitudes of frame f.  Vector-memory operations of a
 // wave retire in issue order and share one counter, so a load issued behind its own frame's 18 stores can only be waited
 // for together with them — and a store takes microseconds to be acknowledged.  Here the wait in front of window(f) covers
 // the loads of frame f and, older than them, only the stores of frame f-2.  The magnitudes of the previous frame ride along
 // in 18 registers.  (tools/ubench/spec_abl.hip, profiles/r02_spectrum_ablation.md: 3.43 -> 3.16 ms on the C5 signal; stores
 // that bypass L2 allocation — they are never read again by this kernel — another 0.1-0.3 ms.)
-constexpr int kSpecChunk = 32;
+#ifndef NAE_SPEC_CHUNK
+#define NAE_SPEC_CHUNK 32
+#endif
+constexpr int kSpecChunk = NAE_SPEC_CHUNK;
 #ifndef NAE_SPEC_STORE_AUX
 #define NAE_SPEC_STORE_AUX 2
 #endif
@@ -154,7 +156,10 @@ __global__ __launch_bounds__(kThreads, 4) void spectrum_stereo_kernel(const floa
         }
         wave_lds_sync();
     };
-    float4 raw[8];
+    // consecutive frames overlap by 768 of 1024 sample-frames = 6 of the 8 rows of the FFT input layout (pair index
+    // n = lane + 64 j, hop = 128 pairs = 2 rows): the raw samples stay in registers and a frame loads only its last 2 rows,
+    // so every input byte is read once
+    float4 raw[8], pre[2];
     if (f0 < f1) {
         const float* base = sbase + 2 * ((long long)f0 * NAE_HOP);
 #pragma unroll
@@ -172,13 +177,17 @@ __global__ __launch_bounds__(kThreads, 4) void spectrum_stereo_kernel(const floa
         if (f > f0) store_frame(f - 1);
         if (f + 1 < f1) {
             const float* base = sbase + 2 * ((long long)(f + 1) * NAE_HOP);
-#pragma unroll
-            for (int j = 0; j < 8; j++) raw[j] = *reinterpret_cast<const float4*>(base + 256 * j);
+            pre[0] = *reinterpret_cast<const float4*>(base + 256 * 6);
+            pre[1] = *reinterpret_cast<const float4*>(base + 256 * 7);
         }
         channel(v0, ma);
         __builtin_amdgcn_sched_barrier(0);      // keep the two channels apart: interleaved, their live values exceed the register budget
         channel(v1, mb);
         __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 6; j++) raw[j] = raw[j + 2];
+        raw[6] = pre[0];
+        raw[7] = pre[1];
     }
     if (f1 > f0) store_frame(f1 - 1);
 }
