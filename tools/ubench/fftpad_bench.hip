@@ -70,7 +70,7 @@ __global__ __launch_bounds__(1024) void bench_kernel(const cf* __restrict__ w512
             wave_lds_sync();
             dft8_fwd(v);
         }
-        if (kMode == 1 || kMode == 2) {
+        if (kMode == 1 || kMode == 2 || (kMode == 6 && !(wave & 1))) {
             dft8_fwd(v);
 #pragma unroll
             for (int q = 1; q < 8; q++) v[q] = cmul_tw(v[q], ta[q - 1]);
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(1024) void bench_kernel(const cf* __restrict__ w512
             }
             dft8_fwd(v);
         }
-        if (kMode == 3) {
+        if (kMode == 3 || (kMode == 6 && (wave & 1))) {
             cf t[7];
 #pragma unroll
             for (int q = 0; q < 7; q++) t[q] = lds_ld(L.twa + 64 * q);
@@ -157,6 +157,7 @@ static double run(int n_cu, const Cfg& cfg, int iters, const cf* d_w, unsigned l
     std::vector<unsigned long long> h((size_t)grid * waves);
     CK(hipMemcpy(h.data(), d_out, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     std::sort(h.begin(), h.end());
+    if (kMode == 6) printf("| (mode 6 detail: quartiles of cycles per iteration per wave) | %d | %.0f / %.0f / %.0f | |\n", cfg.waves_per_simd, (double)h[h.size() / 4] / iters, (double)h[h.size() / 2] / iters, (double)h[3 * h.size() / 4] / iters);
     return (double)h[h.size() / 2] / iters;          // cycles per FFT per wave
 }
 
@@ -176,11 +177,11 @@ int main(int argc, char** argv)
     CK(hipMalloc(&d_out, sizeof(unsigned long long) * n_cu * 2 * 16));
     CK(hipMalloc(&d_sink, sizeof(float) * n_cu * 2 * 1024));
     const Cfg cfgs[] = {{1, 256, 1}, {2, 512, 1}, {3, 768, 1}, {4, 1024, 1}, {6, 768, 2}, {8, 1024, 2}};
-    const char* names[6] = {"fft512_pad, both transposes through LDS (twiddles from LDS)", "same, twiddles in registers", "vector work only (no LDS access)", "LDS traffic only (no arithmetic)", "transpose 1 across lanes (permlane / DPP), twiddles from LDS", "transpose 1 across lanes, twiddles in registers"};
+    const char* names[7] = {"fft512_pad, both transposes through LDS (twiddles from LDS)", "same, twiddles in registers", "vector work only (no LDS access)", "LDS traffic only (no arithmetic)", "transpose 1 across lanes (permlane / DPP), twiddles from LDS", "transpose 1 across lanes, twiddles in registers", "even waves: vector work only; odd waves: LDS traffic only (median over ALL waves)"};
     printf("# padded 512-point FFT: cycles per FFT per wave / per CU-FFT-slot, by waves per SIMD (tools/ubench/fftpad_bench.hip)\n\n");
     printf("per FFT: ~250 vector instructions, 16 ds_write_b64, 16 ds_read_b64 (+ 14 table reads in mode 0 and 3)\n\n");
     printf("| mode | waves/SIMD | cycles per FFT per wave | cycles per FFT per CU (= per wave / waves per CU) |\n|---|---|---|---|\n");
-    for (int mode = 0; mode < 6; mode++)
+    for (int mode = 0; mode < 7; mode++)
         for (const Cfg& cfg : cfgs) {
             double c = 0;
             if (mode == 0) c = run<0>(n_cu, cfg, iters, d_w, d_out, d_sink);
@@ -189,6 +190,7 @@ int main(int argc, char** argv)
             if (mode == 3) c = run<3>(n_cu, cfg, iters, d_w, d_out, d_sink);
             if (mode == 4) c = run<4>(n_cu, cfg, iters, d_w, d_out, d_sink);
             if (mode == 5) c = run<5>(n_cu, cfg, iters, d_w, d_out, d_sink);
+            if (mode == 6) c = run<6>(n_cu, cfg, iters, d_w, d_out, d_sink);
             printf("| %s | %d | %.0f | %.1f |\n", names[mode], cfg.waves_per_simd, c, c / (4.0 * cfg.waves_per_simd));
         }
     return 0;
