@@ -254,12 +254,17 @@ __global__ __launch_bounds__(kPipeThreads, 6) void pv_pipe_kernel(SigViewD src, 
             }
             PIPE_BARRIER(t, 1);                               // B: R2 may overwrite Y
             if (active) {
-                fft512_pad(zs, L);
+                fft512_pad_a(zs, L);
+                // (the synthesis window is requested now: its round trip hides behind passes B and C)
+                cf wn[8];
+#pragma unroll
+                for (int r = 0; r < 8; r++) wn[r] = lds_ld(hw + 64 * r);
+                fft512_pad_bc(zs, L);
                 // zs[r] = conj(z[n]) * 512 (x 4), n = lane + 64 r  ->  time samples 2n, 2n+1, windowed
                 float y[4][4];
 #pragma unroll
                 for (int r = 0; r < 8; r++) {
-                    const cf w = lds_ld(hw + 64 * r);
+                    const cf w = wn[r];
                     y[r >> 1][2 * (r & 1)] = zs[r].x * w.x;
                     y[r >> 1][2 * (r & 1) + 1] = -(zs[r].y * w.y);   // the sign undoes the conjugation
                 }

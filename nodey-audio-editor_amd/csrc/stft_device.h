@@ -186,9 +186,14 @@ __device__ __forceinline__ void fill_twa(cf* twa, const cf* __restrict__ w512, i
 // pass A (registers + the read-only twiddle table): may run while another wave still reads this wave's scratch
 __device__ __forceinline__ void fft512_pad_a(cf (&v)[8], const FftLds& L)
 {
+    // the twiddle reads are issued in front of the butterflies that hide their latency (the accesses are volatile, so the
+    // compiler keeps this order)
+    cf w[7];
+#pragma unroll
+    for (int q = 0; q < 7; q++) w[q] = lds_ld(L.twa + 64 * q);
     dft8_fwd(v);
 #pragma unroll
-    for (int q = 1; q < 8; q++) v[q] = cmul_tw(v[q], lds_ld(L.twa + 64 * (q - 1)));
+    for (int q = 1; q < 8; q++) v[q] = cmul_tw(v[q], w[q - 1]);
 }
 
 // transposes, passes B and C
@@ -200,9 +205,14 @@ __device__ __forceinline__ void fft512_pad_bc(cf (&v)[8], const FftLds& L)
 #pragma unroll
     for (int j = 0; j < 8; j++) v[j] = lds_ld(L.t1r + 8 * j);
     wave_lds_sync();
-    dft8_fwd(v);
+    {
+        cf w[7];
 #pragma unroll
-    for (int p = 1; p < 8; p++) v[p] = cmul_tw(v[p], lds_ld(L.twb + p));
+        for (int p = 1; p < 8; p++) w[p - 1] = lds_ld(L.twb + p);
+        dft8_fwd(v);
+#pragma unroll
+        for (int p = 1; p < 8; p++) v[p] = cmul_tw(v[p], w[p - 1]);
+    }
 #pragma unroll
     for (int p = 0; p < 8; p++) lds_st(L.t2w + 8 * p, v[p]);
     wave_lds_sync();
