@@ -289,7 +289,18 @@ __global__ void pv_scan_kernel(uint32_t* __restrict__ sums, long long n_sc, int 
 }
 
 // rate transposer: out[j] = sum_i tab(phase)[i] * v[idx - 7 + i],  pos = j * step (Q32.32)
-struct RsParams { unsigned long long step_q32; long long src_len; long long out_len; int ch; long long j_begin; };
+struct RsParams { unsigned long long step_q32; long long src_len; long long out_len; int ch; long long j_begin; int rot; };
+
+// LDS slot of coefficient row ph in the tiled kernels.  Neighbouring outputs advance the phase by a fixed amount (24.2
+// rows at the default +3 semitones), and with rows stored in order every other lane of a 16-lane read group lands on the
+// same banks (3-way conflicts on each of the 8 coefficient reads of an output).  Rotating the 7-bit row number right by
+// `rot` makes the bank group of a row depend on bits rot..rot+3 of the phase; the launcher picks the rotation that
+// spreads the lanes of this ratio best (rs_pick_rot).  Row NAE_RS_PHASES (read as "ph + 1" of the last phase) keeps its place.
+__host__ __device__ __forceinline__ unsigned rs_slot(unsigned ph, int rot)
+{
+    return ph >= NAE_RS_PHASES ? ph : (ph >> rot) | ((ph & ((1u << rot) - 1u)) << (7 - rot));
+}
+static_assert(NAE_RS_PHASES == 128, "rs_slot rotates a 7-bit row number");
 
 __global__ __launch_bounds__(256) void resample_kernel(SigViewD src, RsParams p, long long n_streams,
                                                       const float* __restrict__ tab, OutViewD out)
@@ -354,8 +365,8 @@ __device__ __forceinline__ void rs_apply_stereo(const float* stab, const float* 
         const unsigned frac = (unsigned)lo;
         const unsigned ph = frac >> 25;
         const float alpha = (float)(frac & 0x1FFFFFFu) * (1.0f / 33554432.0f);
-        const float4* t0 = reinterpret_cast<const float4*>(stab + ph * kRsRow);
-        const float4* t1 = reinterpret_cast<const float4*>(stab + (ph + 1) * kRsRow);
+        const float4* t0 = reinterpret_cast<const float4*>(stab + rs_slot(ph, p.rot) * kRsRow);
+        const float4* t1 = reinterpret_cast<const float4*>(stab + rs_slot(ph + 1, p.rot) * kRsRow);
         float coef[NAE_RS_TAPS];
 #pragma unroll
         for (int q = 0; q < NAE_RS_TAPS / 4; q++) {
@@ -397,7 +408,7 @@ __global__ __launch_bounds__(256) void resample_tile_kernel(SigViewD src, RsPara
     float* stab = reinterpret_cast<float*>(rs_smem);                           // (PHASES+1) x kRsRow
     float* stage = stab + (NAE_RS_PHASES + 1) * kRsRow;                        // stereo: [NS][span_alloc][2]; else [ch][span_alloc]
     for (int i = threadIdx.x; i < (NAE_RS_PHASES + 1) * NAE_RS_TAPS; i += 256)
-        stab[(i / NAE_RS_TAPS) * kRsRow + (i % NAE_RS_TAPS)] = tab[i];
+        stab[rs_slot(i / NAE_RS_TAPS, p.rot) * kRsRow + (i % NAE_RS_TAPS)] = tab[i];
     const long long s0 = (long long)blockIdx.y * NS;
     const long long j0 = p.j_begin + (long long)blockIdx.x * kRsOut;
     long long j1 = j0 + kRsOut;
@@ -469,8 +480,8 @@ __global__ __launch_bounds__(256) void resample_tile_kernel(SigViewD src, RsPara
             const unsigned frac = (unsigned)lo;
             const unsigned ph = frac >> 25;
             const float alpha = (float)(frac & 0x1FFFFFFu) * (1.0f / 33554432.0f);
-            const float* t0 = stab + ph * kRsRow;
-            const float* t1 = stab + (ph + 1) * kRsRow;
+            const float* t0 = stab + rs_slot(ph, p.rot) * kRsRow;
+            const float* t1 = stab + rs_slot(ph + 1, p.rot) * kRsRow;
             float coef[NAE_RS_TAPS];
 #pragma unroll
             for (int i = 0; i < NAE_RS_TAPS; i++) coef[i] = t0[i] + alpha * (t1[i] - t0[i]);
@@ -505,7 +516,7 @@ __global__ __launch_bounds__(256) void mix_resample_tile_kernel(MixFuseD f, RsPa
     float* stab = reinterpret_cast<float*>(rs_smem);
     float* stage = stab + (NAE_RS_PHASES + 1) * kRsRow;
     for (int i = threadIdx.x; i < (NAE_RS_PHASES + 1) * NAE_RS_TAPS; i += 256)
-        stab[(i / NAE_RS_TAPS) * kRsRow + (i % NAE_RS_TAPS)] = tab[i];
+        stab[rs_slot(i / NAE_RS_TAPS, p.rot) * kRsRow + (i % NAE_RS_TAPS)] = tab[i];
     const long long s0 = (long long)blockIdx.y * NS;
     const long long j0 = (long long)blockIdx.x * kRsOut;
     long long j1 = j0 + kRsOut;
@@ -599,6 +610,37 @@ __global__ __launch_bounds__(256) void mix_resample_tile_kernel(MixFuseD f, RsPa
 
 // ================================================================================================ host side
 using namespace nae;
+
+// rotation of the coefficient rows (rs_slot) with the fewest bank conflicts for this ratio: the 8 x 128-bit reads of an
+// output are served 16 lanes at a time, a row's bank group is 5 * slot mod 16; count the worst multiplicity per group of
+// lanes over the first 256 outputs
+static int rs_pick_rot(unsigned long long step_q32)
+{
+    int best = 0;
+    long best_cost = -1;
+    for (int rot = 0; rot < 4; rot++) {
+        long cost = 0;
+        for (int g = 0; g < 16; g++) {
+            int n0[16] = {0}, n1[16] = {0};
+            unsigned seen0[16], seen1[16];          // distinct rows only: lanes reading the same row share the access
+            for (int l = 0; l < 16; l++) {
+                const unsigned long long pos = (unsigned long long)(16 * g + l) * step_q32;
+                const unsigned ph = (unsigned)(pos & 0xFFFFFFFFull) >> 25;
+                const unsigned s0 = rs_slot(ph, rot), s1 = rs_slot(ph + 1, rot);
+                bool dup0 = false, dup1 = false;
+                for (int k = 0; k < l; k++) { dup0 |= seen0[k] == s0; dup1 |= seen1[k] == s1; }
+                seen0[l] = s0; seen1[l] = s1;
+                if (!dup0) n0[(5 * s0) & 15]++;
+                if (!dup1) n1[(5 * s1) & 15]++;
+            }
+            int m0 = 0, m1 = 0;
+            for (int b = 0; b < 16; b++) { m0 = n0[b] > m0 ? n0[b] : m0; m1 = n1[b] > m1 ? n1[b] : m1; }
+            cost += m0 + m1;
+        }
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = rot; }
+    }
+    return best;
+}
 
 static inline SigViewD to_view(const nae_sig* s)
 {
@@ -737,7 +779,7 @@ int nae_launch_resample(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig*
                         size_t n_streams, const float* d_tab, const nae_sig* out, size_t j_begin, size_t j_end)
 {
     if (j_end <= j_begin || n_streams == 0) return NAE_OK;
-    RsParams p{pl->step_q32, (long long)src_len, (long long)j_end, ch, (long long)j_begin};
+    RsParams p{pl->step_q32, (long long)src_len, (long long)j_end, ch, (long long)j_begin, rs_pick_rot(pl->step_q32)};
     const size_t count = j_end - j_begin;
     // tiled kernel while one tile's source span fits the staging buffer (rho <= 4), else the direct kernel
     const double rho = (double)pl->step_q32 / 4294967296.0;
@@ -792,7 +834,7 @@ int nae_launch_mix_resample(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_
     if (ctx->dbg_no_mix_fuse || !inter16(a) || !inter16(b) || !mix_ok || span_need > kRsMaxSpan || span_alloc > 1536 || n_streams == 0 ||
         pl->mid_len == 0 || S == 0)
         return 1;
-    RsParams p{pl->step_q32, (long long)S, (long long)pl->mid_len, 2, 0};
+    RsParams p{pl->step_q32, (long long)S, (long long)pl->mid_len, 2, 0, rs_pick_rot(pl->step_q32)};
     const size_t lds = ((NAE_RS_PHASES + 1) * kRsRow + (size_t)2 * span_alloc * 4) * sizeof(float);
     const unsigned gx = (unsigned)((pl->mid_len + kRsOut - 1) / kRsOut);
     const size_t per_launch = (size_t)65535 * 4;
