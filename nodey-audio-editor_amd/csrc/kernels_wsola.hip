@@ -109,14 +109,21 @@ __global__ __launch_bounds__(1024 / NC, 4) void st_td_kernel(DView in, TdParams 
     constexpr int T = G::THREADS;
     extern __shared__ __attribute__((aligned(16))) float td_smem[];
     const int ng = p.ovl * CH / 4;                       // 4-float groups per candidate
-    float* win = td_smem;                                // [ROWS][S] units
-    float* mid = win + G::ROWS * p.S * CH;               // [ovl*CH] (+16 pad)
+    // kReuse (throughput shape): two window buffers.  The frames a sequence copies to the output (body + new tail) are most
+    // of the NEXT sequence's seek window, so they are dropped into the other buffer on their way through the registers
+    // and only the part of the next window outside the copied range is fetched again: every input frame is read about
+    // once instead of twice.
+    constexpr bool kReuse = NC >= 4;
+    const int wsz = G::ROWS * p.S * CH;
+    float* win = td_smem;                                // [1 or 2][ROWS][S] units
+    float* mid = win + (kReuse ? 2 : 1) * wsz;           // [ovl*CH] (+16 pad)
     float* ramp1 = mid + p.ovl * CH + 16;                // [ovl] cross-fade weights (stereo)
     float* ramp2 = ramp1 + p.ovl;
     __shared__ Best wave_best[G::WAVES];
     __shared__ int s_off, s_nan0;
 
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    int tid = threadIdx.x;
+    const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long long s = blockIdx.x;
     const float* sbase = in.v.base + s * in.v.ss;
     float* obase = out.o.base + s * out.o.ss;
@@ -143,7 +150,7 @@ __global__ __launch_bounds__(1024 / NC, 4) void st_td_kernel(DView in, TdParams 
     const int b = w * G::LANES + bl;
     const int c0 = G::R * b + pp;                        // this thread's candidates: c0 + P*q, q < NC
     const int wave_c0 = G::R * (w * G::LANES);           // smallest candidate of the wave
-    const float* xrow = win + (pp * p.S + b) * CH;
+    const int xoff = (pp * p.S + b) * CH;
 
     // window of the sequence that starts at frame `at`: global -> registers -> LDS.  The loads are issued one
     // sequence ahead (the positions do not depend on the audio) so their latency hides behind the scoring loop.
@@ -155,34 +162,41 @@ __global__ __launch_bounds__(1024 / NC, 4) void st_td_kernel(DView in, TdParams 
             if (u < nunits) pf[j] = ld_frame<CH>(in, sbase, at + u);
         }
     };
-    auto window_store = [&]() {
+    auto put_unit = [&](float* wn, int u, const Frame<CH>& f) {
+        const int row = u % G::R, col = u / G::R;
+#pragma unroll
+        for (int c = 0; c < CH; c++) wn[(row * p.S + col) * CH + c] = f.x[c];
+        if (row < G::P - 1 && col >= 1) {
+#pragma unroll
+            for (int c = 0; c < CH; c++) wn[((G::R + row) * p.S + col - 1) * CH + c] = f.x[c];
+        }
+    };
+    auto window_store = [&](float* wn) {
 #pragma unroll
         for (int j = 0; j < G::PF; j++) {
             const int u = tid + j * T;
-            if (u < nunits) {
-                const int row = u % G::R, col = u / G::R;
-#pragma unroll
-                for (int c = 0; c < CH; c++) win[(row * p.S + col) * CH + c] = pf[j].x[c];
-                if (row < G::P - 1 && col >= 1) {
-#pragma unroll
-                    for (int c = 0; c < CH; c++) win[((G::R + row) * p.S + col - 1) * CH + c] = pf[j].x[c];
-                }
-            }
+            if (u < nunits) put_unit(wn, u, pf[j]);
         }
     };
 
     long long ip = p.ip0, op = p.op0;
     double skip = p.skip0;
     bool begin = p.begin0 != 0;
+    float* wcur = win;
     if (!begin && p.nseq > 0) {
         window_load(ip);
-        window_store();
+        window_store(wcur);
     }
     if (tid == 0) s_nan0 = 0;
     __syncthreads();
 
 #pragma unroll 1
     for (long long k = 0; k < p.nseq; k++) {
+        // Values derived from the thread index (LDS offsets of the copy and window stores, ramp addresses ...) are invariant
+        // across sequences; hoisted out of this loop they exceed the register budget and are spilled — and a scratch line
+        // re-read once per sequence has left the L2 by then (measured: +10 KB of HBM reads per sequence and stream).
+        // Hiding the index from the optimiser once per sequence makes it recompute them instead (a few dozen instructions).
+        asm volatile("" : "+v"(tid));
         // where the next sequence starts (the library's skip bookkeeping, in its order of operations)
         double skip_n = skip;
         if (begin) {
@@ -198,6 +212,8 @@ __global__ __launch_bounds__(1024 / NC, 4) void st_td_kernel(DView in, TdParams 
         // streams other workgroups hide it and the 12 registers are better spent on occupancy
         constexpr bool kAhead = NC < 4;
         if (more && kAhead) window_load(ip_n);
+        float* wnext = kReuse ? (wcur == win ? win + wsz : win) : win;
+        const float* xrow = wcur + xoff;
 
         int offset = 0;
         if (!begin) {
@@ -288,7 +304,7 @@ __global__ __launch_bounds__(1024 / NC, 4) void st_td_kernel(DView in, TdParams 
             // ---- cross-fade the candidate into the stored tail
             for (int i = tid; i < p.ovl && op + i < p.out_limit; i += T) {
                 const int u = best + i;
-                const float* xu = win + ((u % G::R) * p.S + u / G::R) * CH;
+                const float* xu = wcur + ((u % G::R) * p.S + u / G::R) * CH;
                 Frame<CH> y;
                 if (CH == 2) {
                     const float f1 = ramp1[i], f2 = ramp2[i];
@@ -308,6 +324,13 @@ __global__ __launch_bounds__(1024 / NC, 4) void st_td_kernel(DView in, TdParams 
         }
         // ---- body of the sequence and the new tail: loads of CP frames per thread in flight before their stores
         const long long bsrc = ip + offset;
+        // copied frame i (0 <= i < body + ovl) is unit i + un0 of the next window
+        const int un0 = (int)(bsrc - ip_n);
+        const bool keep = kReuse && more;
+        auto keep_unit = [&](int i, const Frame<CH>& f) {
+            const int u = i + un0;
+            if (keep && u >= 0 && u < nunits) put_unit(wnext, u, f);
+        };
         Frame<CH> tail{};
         if (tid < p.ovl) tail = ld_frame<CH>(in, sbase, bsrc + p.body + tid);
         Frame<CH> tail2{};
@@ -323,9 +346,12 @@ __global__ __launch_bounds__(1024 / NC, 4) void st_td_kernel(DView in, TdParams 
             for (int j = 0; j < G::CP; j++) {
                 const int i = i0 + j * T + tid;
                 if (i < p.body && op + i < p.out_limit) st_frame<CH>(out, obase, op + i, cp[j]);
+                if (i < p.body) keep_unit(i, cp[j]);
             }
         }
         op += p.body;
+        if (tid < p.ovl) keep_unit(p.body + tid, tail);
+        if (tid + T < p.ovl) keep_unit(p.body + tid + T, tail2);
         __syncthreads();                                 // the cross-fade has read the old tail and the old window
         if (tid < p.ovl) {
 #pragma unroll
@@ -336,9 +362,19 @@ __global__ __launch_bounds__(1024 / NC, 4) void st_td_kernel(DView in, TdParams 
             for (int c = 0; c < CH; c++) mid[(tid + T) * CH + c] = tail2.x[c];
         }
         if (more) {
-            if (!kAhead) window_load(ip_n);
-            window_store();
+            if (kReuse) {
+                // the units of the next window that the copy did not pass: in front of it (a large offset) or behind it
+                const int copied = p.body + p.ovl;
+                for (int u = tid; u < nunits; u += T) {
+                    const int i = u - un0;
+                    if (i < 0 || i >= copied) put_unit(wnext, u, ld_frame<CH>(in, sbase, ip_n + u));
+                }
+            } else {
+                if (!kAhead) window_load(ip_n);
+                window_store(wnext);
+            }
         }
+        wcur = wnext;
         skip = skip_n;
         ip = ip_n;
         __syncthreads();
@@ -378,7 +414,7 @@ int st_launch_td(nae_ctx* ctx, const StCfg& c, const StView& in, const TdRange& 
     p.ip0 = r.ip0; p.op0 = r.op0; p.nseq = r.nseq; p.skip0 = r.skip0; p.begin0 = r.begin0; p.out_limit = r.out_limit;
     p.S = td_row_stride(c.ch, c.ovl, nc);
     const int P = 4 / c.ch, rows = nc * P + P - 1;
-    const size_t lds = ((size_t)rows * p.S * c.ch + (size_t)c.ovl * c.ch + 16 + 2 * (size_t)c.ovl) * sizeof(float);
+    const size_t lds = ((size_t)(nc >= 4 ? 2 : 1) * rows * p.S * c.ch + (size_t)c.ovl * c.ch + 16 + 2 * (size_t)c.ovl) * sizeof(float);
     if (lds > 60 * 1024) return nae_fail(ctx, NAE_ERR_INVALID, "WSOLA window does not fit LDS");
     const dim3 grid((unsigned)n_streams);
 #define NAE_TD(CHN, NCN) NAE_KLAUNCH(ctx, "st_td_kernel", (st_td_kernel<CHN, NCN>), grid, dim3(1024 / NCN), lds, ctx->stream, \
