@@ -253,6 +253,12 @@ typedef struct nae_swr nae_swr;
 int nae_swr_create(nae_ctx* ctx, int in_fmt, int in_rate, int in_channels, int out_rate, nae_swr** h);
 int nae_swr_convert_host(nae_swr* h, const void* const* planes_host, size_t n_in, float* outL_host, float* outR_host,
                          size_t max_out, size_t* n_out);
+/* The same with DEVICE output planes and nothing waited for: the upload, the conversion and the two planes are queued on
+ * the context's stream and *n_out (known from frame counts alone) is returned at once.  The caller keeps planes_host alive
+ * until it has waited for the stream (nae_sync / nae_poll).  For hosts that queue several frames — or several inputs of a
+ * mixer — behind one wait; results are those of nae_swr_convert_host. */
+int nae_swr_convert(nae_swr* h, const void* const* planes_host, size_t n_in, float* outL_dev, float* outR_dev,
+                    size_t max_out, size_t* n_out);
 size_t nae_swr_buffered(nae_swr* h);   /* output frames ready without more input */
 int nae_swr_destroy(nae_swr* h);
 /* mono -> interleaved stereo with gain (the rematrix step above), device pointers */

@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = [
     "nae_to_f32_interleaved", "nae_clamp_f32", "nae_stretch_plan_make", "nae_stretch_block_f32",
     "nae_debug_pv_tile_phase", "nae_stretch_create", "nae_stretch_put", "nae_stretch_put_host", "nae_stretch_flush",
     "nae_stretch_available", "nae_stretch_receive", "nae_stretch_receive_host", "nae_stretch_destroy",
-    "nae_swr_create", "nae_swr_convert_host", "nae_swr_buffered", "nae_swr_destroy", "nae_mono_to_stereo_f32",
+    "nae_swr_create", "nae_swr_convert_host", "nae_swr_convert", "nae_swr_buffered", "nae_swr_destroy", "nae_mono_to_stereo_f32",
     "nae_spectrum_frames", "nae_spectrum_block_f32", "nae_spectrum_create", "nae_spectrum_put",
     "nae_spectrum_available", "nae_spectrum_receive", "nae_spectrum_destroy", "nae_graph4_run",
     "nae_wsola_plan_make", "nae_wsola_block_f32", "nae_wsola_create", "nae_wsola_put", "nae_wsola_put_host",
@@ -140,7 +140,8 @@ def load_library() -> C.CDLL:
         "nae_stretch_available": (sz, [vp]), "nae_stretch_receive": (i, [vp, vp, sz, P(sz)]),
         "nae_stretch_receive_host": (i, [vp, vp, sz, P(sz)]), "nae_stretch_destroy": (i, [vp]),
         "nae_swr_create": (i, [vp, i, i, i, i, P(vp)]),
-        "nae_swr_convert_host": (i, [vp, P(vp), sz, vp, vp, sz, P(sz)]), "nae_swr_buffered": (sz, [vp]),
+        "nae_swr_convert_host": (i, [vp, P(vp), sz, vp, vp, sz, P(sz)]), "nae_swr_convert": (i, [vp, P(vp), sz, vp, vp, sz, P(sz)]),
+        "nae_swr_buffered": (sz, [vp]),
         "nae_swr_destroy": (i, [vp]), "nae_mono_to_stereo_f32": (i, [vp, vp, vp, sz, f]),
         "nae_spectrum_frames": (sz, [sz]), "nae_spectrum_block_f32": (i, [vp, P(Sig), sz, i, sz, vp, sz]),
         "nae_spectrum_create": (i, [vp, i, i, i, P(vp)]), "nae_spectrum_put": (i, [vp, vp, sz]),

@@ -261,6 +261,70 @@ int nae_swr_create(nae_ctx* ctx, int in_fmt, int in_rate, int in_channels, int o
 
 size_t nae_swr_buffered(nae_swr* h) { return h ? h->n_out - h->n_read : 0; }
 
+/* upload + format conversion of one call's input, appended to the input FIFO (or, equal rates, straight to the output
+ * FIFO: a wire); queued on the stream, nothing waited for */
+static int swr_feed(nae_swr* h, const void* const* planes, size_t n_in)
+{
+    nae_ctx* ctx = h->ctx;
+    int rc;
+    if (h->flushed) return nae_fail(ctx, NAE_ERR_STATE, "input after drain");
+    const bool planar = (h->in_fmt == NAE_FMT_FLTP || h->in_fmt == NAE_FMT_S16P || h->in_fmt == NAE_FMT_S32P);
+    const int bps = (h->in_fmt == NAE_FMT_S16 || h->in_fmt == NAE_FMT_S16P) ? 2 : 4;
+    const int n_planes = planar ? h->in_ch : 1;
+    const size_t plane_bytes = n_in * bps * (planar ? 1 : h->in_ch);
+    const size_t stride = (plane_bytes + 255) / 256 * 256;
+    if ((rc = devbuf_reserve(ctx, h->raw, stride * n_planes / sizeof(float) + 64))) return rc;
+    unsigned char* raw = reinterpret_cast<unsigned char*>(h->raw.p);
+    const void* dp[2] = {raw, raw + stride};
+    for (int p = 0; p < n_planes; p++) {
+        if (!planes[p]) return nae_fail(ctx, NAE_ERR_INVALID, "null plane pointer");
+        hipError_t e = hipMemcpyAsync(raw + p * stride, planes[p], plane_bytes, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) return nae_check(ctx, e, "hipMemcpyAsync(swr in)");
+    }
+    // format -> f32 (K6 scaling), mono -> stereo (L = R = m / sqrt(2), swr's default float rematrix)
+    DevFifo& dstf = h->identity ? h->out : h->in;
+    size_t& total = h->identity ? h->n_out : h->n_in;
+    if ((rc = fifo_reserve_interleaved(ctx, dstf, total, total + n_in, 2))) return rc;
+    float* tail = dstf.cur.p + (total - dstf.base) * 2;
+    if (h->in_ch == 2) {
+        if ((rc = nae_to_f32_interleaved(ctx, h->in_fmt, dp, n_in, 2, tail))) return rc;
+    } else {
+        if ((rc = devbuf_reserve(ctx, h->f32, n_in))) return rc;
+        if ((rc = nae_to_f32_interleaved(ctx, h->in_fmt, dp, n_in, 1, h->f32.p))) return rc;
+        if ((rc = nae_mono_to_stereo_f32(ctx, h->f32.p, tail, n_in, 0.70710678118654752440f))) return rc;
+    }
+    total += n_in;
+    dstf.cur.len = (total - dstf.base) * 2;
+    return NAE_OK;
+}
+
+/* the next min(buffered, max_out) output frames as two device planes; queued on the stream */
+static int swr_emit(nae_swr* h, float* dL, float* dR, size_t max_out, size_t* n_out)
+{
+    nae_ctx* ctx = h->ctx;
+    size_t n = h->n_out - h->n_read;
+    if (n > max_out) n = max_out;
+    *n_out = n;
+    if (n == 0) return NAE_OK;
+    float* planes_out[2] = {dL, dR};
+    int rc = nae_deinterleave_f32(ctx, h->out.cur.p + (h->n_read - h->out.base) * 2, planes_out, n, 2);
+    if (rc) return rc;
+    h->n_read += n;
+    if (h->n_read - h->out.base > (1u << 16)) return fifo_drop_interleaved(ctx, h->out, h->n_read, h->n_out, 2);
+    return NAE_OK;
+}
+
+static int swr_convert_common(nae_swr* h, const void* const* planes, size_t n_in)
+{
+    int rc;
+    if (planes && n_in) {
+        if ((rc = swr_feed(h, planes, n_in))) return rc;
+    } else if (!planes) {
+        h->flushed = true;
+    }
+    return h->identity ? NAE_OK : swr_run(h);
+}
+
 /* swr_convert(ctx, out, max_out, in, n_in): consumes all n_in frames, delivers at most max_out, keeps the rest; planes == NULL
  * drains (audio-amix.cpp:281-282) */
 int nae_swr_convert_host(nae_swr* h, const void* const* planes, size_t n_in, float* outL, float* outR, size_t max_out, size_t* n_out)
@@ -269,55 +333,32 @@ int nae_swr_convert_host(nae_swr* h, const void* const* planes, size_t n_in, flo
     nae_ctx* ctx = h->ctx;
     *n_out = 0;
     int rc;
-    if (planes && n_in) {
-        if (h->flushed) return nae_fail(ctx, NAE_ERR_STATE, "input after drain");
-        const bool planar = (h->in_fmt == NAE_FMT_FLTP || h->in_fmt == NAE_FMT_S16P || h->in_fmt == NAE_FMT_S32P);
-        const int bps = (h->in_fmt == NAE_FMT_S16 || h->in_fmt == NAE_FMT_S16P) ? 2 : 4;
-        const int n_planes = planar ? h->in_ch : 1;
-        const size_t plane_bytes = n_in * bps * (planar ? 1 : h->in_ch);
-        const size_t stride = (plane_bytes + 255) / 256 * 256;
-        if ((rc = devbuf_reserve(ctx, h->raw, stride * n_planes / sizeof(float) + 64))) return rc;
-        unsigned char* raw = reinterpret_cast<unsigned char*>(h->raw.p);
-        const void* dp[2] = {raw, raw + stride};
-        for (int p = 0; p < n_planes; p++) {
-            if (!planes[p]) return nae_fail(ctx, NAE_ERR_INVALID, "null plane pointer");
-            hipError_t e = hipMemcpyAsync(raw + p * stride, planes[p], plane_bytes, hipMemcpyHostToDevice, ctx->stream);
-            if (e != hipSuccess) return nae_check(ctx, e, "hipMemcpyAsync(swr in)");
-        }
-        // format -> f32 (K6 scaling), mono -> stereo (L = R = m / sqrt(2), swr's default float rematrix), appended to the
-        // input FIFO (or straight to the output FIFO when the rates are equal: a wire)
-        DevFifo& dstf = h->identity ? h->out : h->in;
-        size_t& total = h->identity ? h->n_out : h->n_in;
-        if ((rc = fifo_reserve_interleaved(ctx, dstf, total, total + n_in, 2))) return rc;
-        float* tail = dstf.cur.p + (total - dstf.base) * 2;
-        if (h->in_ch == 2) {
-            if ((rc = nae_to_f32_interleaved(ctx, h->in_fmt, dp, n_in, 2, tail))) return rc;
-        } else {
-            if ((rc = devbuf_reserve(ctx, h->f32, n_in))) return rc;
-            if ((rc = nae_to_f32_interleaved(ctx, h->in_fmt, dp, n_in, 1, h->f32.p))) return rc;
-            if ((rc = nae_mono_to_stereo_f32(ctx, h->f32.p, tail, n_in, 0.70710678118654752440f))) return rc;
-        }
-        total += n_in;
-        dstf.cur.len = (total - dstf.base) * 2;
-        (void)hipStreamSynchronize(ctx->stream);     // the caller may reuse its planes
-    } else if (!planes) {
-        h->flushed = true;
-    }
-    if (!h->identity && (rc = swr_run(h))) return rc;
+    if ((rc = swr_convert_common(h, planes, n_in))) return rc;
     size_t n = h->n_out - h->n_read;
     if (n > max_out) n = max_out;
-    if (n == 0) return NAE_OK;
+    if (n == 0) {
+        // the caller may reuse its planes
+        return nae_check(ctx, hipStreamSynchronize(ctx->stream), "swr in");
+    }
     if ((rc = devbuf_reserve(ctx, h->planes, 2 * n))) return rc;
-    float* planes_out[2] = {h->planes.p, h->planes.p + n};
-    if ((rc = nae_deinterleave_f32(ctx, h->out.cur.p + (h->n_read - h->out.base) * 2, planes_out, n, 2))) return rc;
-    hipError_t e = hipMemcpyAsync(outL, planes_out[0], n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(outR, planes_out[1], n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+    float* dL = h->planes.p;
+    float* dR = h->planes.p + n;
+    if ((rc = swr_emit(h, dL, dR, n, &n))) return rc;
+    hipError_t e = hipMemcpyAsync(outL, dL, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(outR, dR, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) return nae_check(ctx, e, "swr out");
-    h->n_read += n;
     *n_out = n;
-    if (h->n_read - h->out.base > (1u << 16)) return fifo_drop_interleaved(ctx, h->out, h->n_read, h->n_out, 2);
     return NAE_OK;
+}
+
+int nae_swr_convert(nae_swr* h, const void* const* planes, size_t n_in, float* outL, float* outR, size_t max_out, size_t* n_out)
+{
+    if (!h || !n_out || (max_out && (!outL || !outR))) return NAE_ERR_INVALID;
+    *n_out = 0;
+    int rc;
+    if ((rc = swr_convert_common(h, planes, n_in))) return rc;
+    return swr_emit(h, outL, outR, max_out, n_out);
 }
 
 int nae_swr_destroy(nae_swr* h)

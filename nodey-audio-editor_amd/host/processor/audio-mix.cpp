@@ -48,6 +48,21 @@ namespace processor
 								   f.sample_rate, f.ch_layout.nb_channels, f.format)
 					);
 			}
+			// the same, queued: DEVICE planes (zero-filled by the caller), nothing waited for; the frame stays alive until the
+			// caller has waited for the stream
+			int convert_queued(const Frame_data* f, float* dev_l, float* dev_r, int S)
+			{
+				if (!h) return 0;
+				size_t got = 0;
+				const int rc = f ? nae_swr_convert(h, reinterpret_cast<const void* const*>(f->data), f->nb_samples, dev_l, dev_r, S, &got)
+								 : nae_swr_convert(h, nullptr, 0, dev_l, dev_r, S, &got);
+				if (rc != NAE_OK)
+					throw infra::Processor::Runtime_error(
+						"Software resampler failed", "Cannot convert audio sample rate or format. Internal error may have occurred.",
+						infra::fmt("nae_swr_convert returned error %d: %s", rc, nae_last_error(gpu::context()))
+					);
+				return (int)got;
+			}
 			// swr_convert(ctx, out, S, in, n): out_* are zero-filled by the caller; returns the frames delivered
 			int convert(const Frame_data* f, float* out_l, float* out_r, int S)
 			{
@@ -173,27 +188,37 @@ namespace processor
 
 		nae_ctx* ctx = gpu::context();
 		gpu::Device_buffer d_in, d_out;
-		std::vector<float> h_in;
 
-		while (!stop_token)
+		// Batching.  The reference takes one frame per input and round and mixes it; a 1152-sample round is
+		// 9 KB per input, so on the GPU a round is all launch and wait.  Here every frame that is ALREADY waiting joins: the
+		// rounds that can be formed from the buffered frames (at most 16) are planned first, then every round's input
+		// conversions (nae_swr_convert: device planes, nothing waited for), its mix and its two downloads are queued, and the
+		// stream is waited for once.  Round by round the arithmetic, the frame sizes, the time stamps and the end-of-stream
+		// rule (:290, :320) are those of the one-round loop; nothing waits for input that has not arrived.
+		constexpr size_t max_batch = 16;
+		struct Round { int S; size_t plane, in_off, out_off; std::shared_ptr<Audio_frame> out; };
+
+		bool finished = false;
+		batch_stats = {};
+		while (!stop_token && !finished)
 		{
 			for (int i = 0; i < input_num; i++)
-			{
-				auto pop_result = input_items[i].get().try_pop();
-				if (!pop_result.has_value())
+				while (buffers[i].size() < max_batch)
 				{
-					if (pop_result.error() == channel_op_status::empty)
+					auto pop_result = input_items[i].get().try_pop();
+					if (!pop_result.has_value())
 					{
-						if (input_items[i].get().eof()) eofs[i] = true;
+						if (pop_result.error() == channel_op_status::empty)
+						{
+							if (input_items[i].get().eof()) eofs[i] = true;
+						}
+						else if (pop_result.error() == channel_op_status::closed)
+							THROW_LOGIC_ERROR("Unexpected channel closed in Audio_amix::process_payload");
+						break;
 					}
-					else if (pop_result.error() == channel_op_status::closed)
-						THROW_LOGIC_ERROR("Unexpected channel closed in Audio_amix::process_payload");
-				}
-				else
 					buffers[i].push_back(pop_result.value());
-			}
+				}
 			bool check = false;
-			count = 0;
 			for (int i = 0; i < input_num; i++)
 				if (buffers[i].empty() && !eofs[i])
 				{
@@ -203,38 +228,69 @@ namespace processor
 				}
 			if (check) continue;
 
-			std::vector<const Frame_data*> frames(input_num, nullptr);
-			for (int i = 0; i < input_num; i++) frames[i] = buffers[i].empty() ? nullptr : buffers[i].front()->data();
-			int S = std::numeric_limits<int>::max();
-			for (auto* f : frames)
-				if (f) S = std::min(S, f->nb_samples);
-			if (S == std::numeric_limits<int>::max()) S = 1152;  // :195
-			time_seconds += S / double(std_sample_rate);          // :199 (pts = END time of the frame)
-			auto new_frame = new_fltp_frame(S, time_seconds);
-			for (int i = 0; i < input_num; i++)
-				if (frames[i]) resamplers[i].open(*frames[i]);  // :206-243 (first frame of each input)
-			// per-input swr_convert into zero-filled planes [i][2][S]
-			const size_t plane = ((size_t)S + 3) / 4 * 4;
-			h_in.assign((size_t)input_num * 2 * plane, 0.0f);
-			for (int i = 0; i < input_num; i++)
+			// plan: round b takes the b-th buffered frame of every input; an input that has ended contributes its converter's
+			// remainder (frame == nullptr); a round with no frame at all (everything ended: the drain round, S = 1152) closes the batch
+			std::vector<Round> rounds;
+			size_t in_floats = 0, out_floats = 0;
+			for (size_t b = 0; b < max_batch; b++)
 			{
-				const int got = resamplers[i].convert(frames[i], &h_in[(2 * i) * plane], &h_in[(2 * i + 1) * plane], S);
-				if (!frames[i] && got < S) count++;  // :290
+				bool any = false, ready = true;
+				int S = std::numeric_limits<int>::max();
+				for (int i = 0; i < input_num; i++)
+				{
+					if (buffers[i].size() > b) { any = true; S = std::min(S, buffers[i][b]->data()->nb_samples); }
+					else if (!eofs[i]) ready = false;
+				}
+				if (!ready || (!any && b > 0)) break;
+				if (!any) S = 1152;  // :195
+				Round r;
+				r.S = S;
+				r.plane = ((size_t)S + 3) / 4 * 4;
+				r.in_off = in_floats;
+				r.out_off = out_floats;
+				in_floats += (size_t)input_num * 2 * r.plane;
+				out_floats += 2 * r.plane;
+				rounds.push_back(std::move(r));
+				if (!any) break;
 			}
-			float* di = static_cast<float*>(d_in.reserve(h_in.size() * sizeof(float)));
-			float* dout = static_cast<float*>(d_out.reserve(2 * plane * sizeof(float)));
-			gpu::check(nae_memcpy_h2d(ctx, di, h_in.data(), h_in.size() * sizeof(float)), "h2d");
-			const float *inL[16], *inR[16];
-			for (int i = 0; i < input_num; i++) { inL[i] = di + (2 * i) * plane; inR[i] = di + (2 * i + 1) * plane; }
-			gpu::check(nae_amix_f32(ctx, inL, inR, volumes.data(), input_num, dout, dout + plane, S), "nae_amix_f32");
-			gpu::check(nae_memcpy_d2h(ctx, new_frame->data()->data[0], dout, S * sizeof(float)), "d2h");
-			gpu::check(nae_memcpy_d2h(ctx, new_frame->data()->data[1], dout + plane, S * sizeof(float)), "d2h");
-			gpu::wait(stop_token);
 
-			for (auto& b : buffers)
-				if (!b.empty()) b.erase(b.begin());
-			push_to_all(output_item, new_frame, stop_token);
-			if (count == input_num) break;  // :320
+			float* di = static_cast<float*>(d_in.reserve(in_floats * sizeof(float)));
+			float* dout = static_cast<float*>(d_out.reserve(out_floats * sizeof(float)));
+			gpu::check(nae_memset(ctx, di, 0, in_floats * sizeof(float)), "nae_memset");  // zero-filled planes [round][i][2][S]
+			size_t done = 0;
+			for (Round& r : rounds)
+			{
+				const size_t b = done;
+				std::vector<const Frame_data*> frames(input_num, nullptr);
+				for (int i = 0; i < input_num; i++) frames[i] = buffers[i].size() > b ? buffers[i][b]->data() : nullptr;
+				time_seconds += r.S / double(std_sample_rate);          // :199 (pts = END time of the frame)
+				r.out = new_fltp_frame(r.S, time_seconds);
+				for (int i = 0; i < input_num; i++)
+					if (frames[i]) resamplers[i].open(*frames[i]);  // :206-243 (first frame of each input)
+				count = 0;
+				const float *inL[16], *inR[16];
+				for (int i = 0; i < input_num; i++)
+				{
+					float* l = di + r.in_off + (size_t)(2 * i) * r.plane;
+					float* rr = l + r.plane;
+					const int got = resamplers[i].convert_queued(frames[i], l, rr, r.S);
+					if (!frames[i] && got < r.S) count++;  // :290
+					inL[i] = l;
+					inR[i] = rr;
+				}
+				float* o = dout + r.out_off;
+				gpu::check(nae_amix_f32(ctx, inL, inR, volumes.data(), input_num, o, o + r.plane, r.S), "nae_amix_f32");
+				gpu::check(nae_memcpy_d2h(ctx, r.out->data()->data[0], o, r.S * sizeof(float)), "d2h");
+				gpu::check(nae_memcpy_d2h(ctx, r.out->data()->data[1], o + r.plane, r.S * sizeof(float)), "d2h");
+				done++;
+				if (count == input_num) { finished = true; break; }  // :320
+			}
+			gpu::wait(stop_token);  // the buffered frames (the uploads' sources) are released only now
+			batch_stats.rounds += done;
+			batch_stats.waits++;
+
+			for (auto& b : buffers) b.erase(b.begin(), b.begin() + std::min(done, b.size()));
+			for (size_t k = 0; k < done; k++) push_to_all(output_item, rounds[k].out, stop_token);
 		}
 		for (auto& out : output_item) out->set_eof();
 	}
@@ -293,47 +349,87 @@ namespace processor
 		Gpu_swr resampler_l, resampler_r;
 		nae_ctx* ctx = gpu::context();
 		gpu::Device_buffer d_in, d_out;
-		std::vector<float> h_in;
 
-		while (!stop_token)
+		// batched like Audio_amix: the rounds that the waiting frames allow are planned, queued and waited for once
+		constexpr size_t max_batch = 16;
+		struct Round { int S; size_t plane, in_off, out_off; std::shared_ptr<Audio_frame> out; };
+		auto intake = [&](Audio_stream& item, std::vector<std::shared_ptr<const Audio_frame>>& buf, bool& eof)
 		{
-			const auto pop_result_l = input_item_l.try_pop();
-			if (!pop_result_l.has_value()) { if (pop_result_l.error() == channel_op_status::empty && input_item_l.eof()) left_eof = true; }
-			else buf_l.push_back(pop_result_l.value());
-			const auto pop_result_r = input_item_r.try_pop();
-			if (!pop_result_r.has_value()) { if (pop_result_r.error() == channel_op_status::empty && input_item_r.eof()) right_eof = true; }
-			else buf_r.push_back(pop_result_r.value());
+			while (buf.size() < max_batch)
+			{
+				const auto pop_result = item.try_pop();
+				if (!pop_result.has_value())
+				{
+					if (pop_result.error() == channel_op_status::empty && item.eof()) eof = true;
+					break;
+				}
+				buf.push_back(pop_result.value());
+			}
+		};
+
+		bool finished = false;
+		batch_stats = {};
+		while (!stop_token && !finished)
+		{
+			intake(input_item_l, buf_l, left_eof);
+			intake(input_item_r, buf_r, right_eof);
 			if ((buf_r.empty() && !right_eof) || (buf_l.empty() && !left_eof))
 			{
 				nae_fiber::this_fiber::yield();
 				continue;
 			}
-			const Frame_data* frame_l = buf_l.empty() ? nullptr : buf_l.front()->data();
-			const Frame_data* frame_r = buf_r.empty() ? nullptr : buf_r.front()->data();
-			int S;  // :176-183 (the reference's if / if / else-if / else chain ends in 1152 unless exactly one side is present)
-			if (frame_r && frame_l) S = std::min(frame_r->nb_samples, frame_l->nb_samples);
-			if (!frame_r && frame_l) S = frame_l->nb_samples;
-			else if (frame_r && !frame_l) S = frame_r->nb_samples;
-			else S = 1152;
-			time_seconds += S / double(48000);
-			auto new_frame = new_fltp_frame(S, time_seconds);
-			if (frame_l) resampler_l.open(*frame_l);
-			if (frame_r) resampler_r.open(*frame_r);
-			const size_t plane = ((size_t)S + 3) / 4 * 4;
-			h_in.assign(4 * plane, 0.0f);
-			const int convert_count_l = resampler_l.convert(frame_l, &h_in[0], &h_in[plane], S);
-			const int convert_count_r = resampler_r.convert(frame_r, &h_in[2 * plane], &h_in[3 * plane], S);
-			float* di = static_cast<float*>(d_in.reserve(h_in.size() * sizeof(float)));
-			float* dout = static_cast<float*>(d_out.reserve(2 * plane * sizeof(float)));
-			gpu::check(nae_memcpy_h2d(ctx, di, h_in.data(), h_in.size() * sizeof(float)), "h2d");
-			gpu::check(nae_bimix_f32(ctx, di, di + plane, di + 2 * plane, di + 3 * plane, bias, dout, dout + plane, S), "nae_bimix_f32");
-			gpu::check(nae_memcpy_d2h(ctx, new_frame->data()->data[0], dout, S * sizeof(float)), "d2h");
-			gpu::check(nae_memcpy_d2h(ctx, new_frame->data()->data[1], dout + plane, S * sizeof(float)), "d2h");
+			std::vector<Round> rounds;
+			size_t in_floats = 0, out_floats = 0;
+			for (size_t b = 0; b < max_batch; b++)
+			{
+				const Frame_data* frame_l = buf_l.size() > b ? buf_l[b]->data() : nullptr;
+				const Frame_data* frame_r = buf_r.size() > b ? buf_r[b]->data() : nullptr;
+				if ((!frame_l && !left_eof) || (!frame_r && !right_eof)) break;
+				if (!frame_l && !frame_r && b > 0) break;
+				int S;  // :176-183 (the reference's if / if / else-if / else chain ends in 1152 unless exactly one side is present)
+				if (frame_r && frame_l) S = std::min(frame_r->nb_samples, frame_l->nb_samples);
+				if (!frame_r && frame_l) S = frame_l->nb_samples;
+				else if (frame_r && !frame_l) S = frame_r->nb_samples;
+				else S = 1152;
+				Round r;
+				r.S = S;
+				r.plane = ((size_t)S + 3) / 4 * 4;
+				r.in_off = in_floats;
+				r.out_off = out_floats;
+				in_floats += 4 * r.plane;
+				out_floats += 2 * r.plane;
+				rounds.push_back(std::move(r));
+				if (!frame_l && !frame_r) break;
+			}
+			float* di = static_cast<float*>(d_in.reserve(in_floats * sizeof(float)));
+			float* dout = static_cast<float*>(d_out.reserve(out_floats * sizeof(float)));
+			gpu::check(nae_memset(ctx, di, 0, in_floats * sizeof(float)), "nae_memset");
+			size_t done = 0;
+			for (Round& r : rounds)
+			{
+				const size_t b = done;
+				const Frame_data* frame_l = buf_l.size() > b ? buf_l[b]->data() : nullptr;
+				const Frame_data* frame_r = buf_r.size() > b ? buf_r[b]->data() : nullptr;
+				time_seconds += r.S / double(48000);
+				r.out = new_fltp_frame(r.S, time_seconds);
+				if (frame_l) resampler_l.open(*frame_l);
+				if (frame_r) resampler_r.open(*frame_r);
+				float* in = di + r.in_off;
+				const int convert_count_l = resampler_l.convert_queued(frame_l, in, in + r.plane, r.S);
+				const int convert_count_r = resampler_r.convert_queued(frame_r, in + 2 * r.plane, in + 3 * r.plane, r.S);
+				float* o = dout + r.out_off;
+				gpu::check(nae_bimix_f32(ctx, in, in + r.plane, in + 2 * r.plane, in + 3 * r.plane, bias, o, o + r.plane, r.S), "nae_bimix_f32");
+				gpu::check(nae_memcpy_d2h(ctx, r.out->data()->data[0], o, r.S * sizeof(float)), "d2h");
+				gpu::check(nae_memcpy_d2h(ctx, r.out->data()->data[1], o + r.plane, r.S * sizeof(float)), "d2h");
+				done++;
+				if (convert_count_r == 0 && convert_count_l == 0) { finished = true; break; }  // :327
+			}
 			gpu::wait(stop_token);
-			if (frame_l) buf_l.erase(buf_l.begin());
-			if (frame_r) buf_r.erase(buf_r.begin());
-			push_to_all(output_item, new_frame, stop_token);
-			if (convert_count_r == 0 && convert_count_l == 0) break;  // :327
+			batch_stats.rounds += done;
+			batch_stats.waits++;
+			buf_l.erase(buf_l.begin(), buf_l.begin() + std::min(done, buf_l.size()));
+			buf_r.erase(buf_r.begin(), buf_r.begin() + std::min(done, buf_r.size()));
+			for (size_t k = 0; k < done; k++) push_to_all(output_item, rounds[k].out, stop_token);
 		}
 		for (auto& out : output_item) out->set_eof();
 	}

@@ -96,4 +96,11 @@ namespace processor
 		void set_eof() { end_of_stream.store(true); }
 		size_t buffered_count() const { return buffered_frames.load(); }
 	};
+
+	// how a batching node's last run went: `rounds` units of the reference's one-per-iteration loop (frames mixed / frames put)
+	// were served behind `waits` waits for the GPU; rounds / waits is the average batch
+	struct Batch_stats
+	{
+		size_t rounds = 0, waits = 0;
+	};
 }

@@ -52,29 +52,51 @@ namespace processor
 			return new_frame;
 		}
 
-		// frame -> device interleaved f32 (extract_samples_interleaved, :150-232, as nae_to_f32_interleaved)
-		float* upload_as_f32(const Frame_data* frame, gpu::Device_buffer& d_raw, gpu::Device_buffer& d_f32)
+		// frames -> device interleaved f32, one after the other (extract_samples_interleaved, :150-232, as
+		// nae_to_f32_interleaved per frame).  Everything is queued on the stream; the frames must stay alive until the caller
+		// has waited for it.  All frames have the channel count of the first.
+		float* upload_as_f32(const std::vector<std::shared_ptr<const Audio_frame>>& frames, gpu::Device_buffer& d_raw,
+							 gpu::Device_buffer& d_f32, size_t* total_samples)
 		{
 			nae_ctx* ctx = gpu::context();
-			const int ch = frame->ch_layout.nb_channels;
-			const int bps = bytes_per_sample(frame->format);
-			if (bps == 0 || frame->format == AV_SAMPLE_FMT_DBL)
-				throw infra::Processor::Runtime_error(
-					"Unsupported sample format", "The processors do not support the given sample format.",
-					infra::fmt("Sample format: %d", frame->format)
-				);
-			const bool planar = sample_fmt_is_planar(frame->format);
-			const int planes = planar ? ch : 1;
-			const size_t plane_bytes = (size_t)frame->nb_samples * bps * (planar ? 1 : ch);
-			const size_t stride = (plane_bytes + 255) / 256 * 256;
-			auto* raw = static_cast<uint8_t*>(d_raw.reserve(stride * planes));
-			float* out = static_cast<float*>(d_f32.reserve((size_t)frame->nb_samples * ch * sizeof(float)));
-			const void* pl[2] = {raw, raw + stride};
-			for (int p = 0; p < planes; p++) gpu::check(nae_memcpy_h2d(ctx, raw + p * stride, frame->data[p], plane_bytes), "h2d");
-			gpu::check(nae_to_f32_interleaved(ctx, frame->format, pl, frame->nb_samples, ch, out), "nae_to_f32_interleaved");
+			const int ch = frames.front()->data()->ch_layout.nb_channels;
+			struct Place { size_t raw_off, stride, plane_bytes, out_off; int planes; };
+			std::vector<Place> place;
+			size_t raw_bytes = 0, out_samples = 0;
+			for (const auto& f : frames)
+			{
+				const Frame_data* frame = f->data();
+				const int bps = bytes_per_sample(frame->format);
+				if (bps == 0 || frame->format == AV_SAMPLE_FMT_DBL)
+					throw infra::Processor::Runtime_error(
+						"Unsupported sample format", "The processors do not support the given sample format.",
+						infra::fmt("Sample format: %d", frame->format)
+					);
+				const bool planar = sample_fmt_is_planar(frame->format);
+				Place p;
+				p.planes = planar ? ch : 1;
+				p.plane_bytes = (size_t)frame->nb_samples * bps * (planar ? 1 : ch);
+				p.stride = (p.plane_bytes + 255) / 256 * 256;
+				p.raw_off = raw_bytes;
+				p.out_off = out_samples * ch;
+				raw_bytes += p.stride * p.planes;
+				out_samples += frame->nb_samples;
+				place.push_back(p);
+			}
+			auto* raw = static_cast<uint8_t*>(d_raw.reserve(raw_bytes));
+			float* out = static_cast<float*>(d_f32.reserve(out_samples * ch * sizeof(float)));
+			for (size_t k = 0; k < frames.size(); k++)
+			{
+				const Frame_data* frame = frames[k]->data();
+				const Place& p = place[k];
+				const void* pl[2] = {raw + p.raw_off, raw + p.raw_off + p.stride};
+				for (int q = 0; q < p.planes; q++)
+					gpu::check(nae_memcpy_h2d(ctx, raw + p.raw_off + q * p.stride, frame->data[q], p.plane_bytes), "h2d");
+				gpu::check(nae_to_f32_interleaved(ctx, frame->format, pl, frame->nb_samples, ch, out + p.out_off), "nae_to_f32_interleaved");
+			}
+			*total_samples = out_samples;
 			return out;
 		}
-
 		// the object soundtouch_process_payload talks to: the phase-vocoder handle (default) or the
 		// SoundTouch-shaped WSOLA chain, chosen by the node's "algorithm" key
 		struct Stretcher
@@ -111,9 +133,10 @@ namespace processor
 			const std::map<std::string, std::shared_ptr<infra::Processor::Product>>& input,
 			const std::map<std::string, std::set<std::shared_ptr<infra::Processor::Product>>>& output,
 			const std::atomic<bool>& stop_token, float velocity, float pitch, const std::string& processor_name,
-			Stretch_algorithm algorithm
+			Stretch_algorithm algorithm, Batch_stats& batch_stats
 		)
 		{
+			batch_stats = {};
 			const auto input_item = infra::get_input_item<Audio_stream>(input, "input");
 			const auto output_stream = infra::get_output_item<Audio_stream>(output, "output");
 			if (!input_item.has_value())
@@ -126,6 +149,7 @@ namespace processor
 			Stretcher soundtouch;
 			gpu::Device_buffer d_raw, d_f32;
 			bool input_stream_eof = false;
+			std::shared_ptr<const Audio_frame> held;  // popped, but with another channel count than the batch in front of it
 			const double time_ratio = 1.0f / velocity;
 			int channel_count = 0, sample_rate = 0;
 			double time_seconds = 0.0;
@@ -149,22 +173,39 @@ namespace processor
 
 			while (!stop_token)
 			{
-				if (!input_stream_eof)
+				if (!input_stream_eof || held)
 				{
-					const auto pop_result = input_stream.try_pop();
-					if (!pop_result.has_value())
+					// Batching: the reference puts one frame per round; here every frame that is already waiting
+					// (at most 16) is uploaded, converted and put as ONE block behind one wait.  The handle's output does not
+					// depend on how its input is cut into puts (tests/test_gpu_stft.py, test_gpu_wsola.py: chunking invariance).
+					constexpr size_t max_batch = 16;
+					std::vector<std::shared_ptr<const Audio_frame>> batch;
+					if (held) batch.push_back(std::move(held));
+					held.reset();
+					while (batch.size() < max_batch && !input_stream_eof)
 					{
-						if (pop_result.error() != channel_op_status::empty)
-							throw infra::Processor::Runtime_error(
-								"Unexpected error when fetching audio frame", processor_name + " encountered an unexpected error.",
-								infra::fmt("Channel fetch error: %d", (int)pop_result.error())
-							);
-						if (input_stream.eof()) input_stream_eof = true;
+						const auto pop_result = input_stream.try_pop();
+						if (!pop_result.has_value())
+						{
+							if (pop_result.error() != channel_op_status::empty)
+								throw infra::Processor::Runtime_error(
+									"Unexpected error when fetching audio frame", processor_name + " encountered an unexpected error.",
+									infra::fmt("Channel fetch error: %d", (int)pop_result.error())
+								);
+							if (input_stream.eof()) input_stream_eof = true;
+							break;
+						}
+						if (!batch.empty() && pop_result.value()->data()->ch_layout.nb_channels != batch.front()->data()->ch_layout.nb_channels)
+						{
+							held = pop_result.value();
+							break;
+						}
+						batch.push_back(pop_result.value());
 					}
-					else
+					if (!batch.empty())
 					{
 						constexpr size_t max_queued_samples = 65536;
-						const Frame_data* frame = pop_result.value()->data();
+						const Frame_data* frame = batch.front()->data();
 						if (!soundtouch.open())
 						{
 							if (frame->sample_rate < 8000 || frame->sample_rate > 48000)  // :371-379
@@ -179,9 +220,12 @@ namespace processor
 							sample_rate = frame->sample_rate;
 						}
 						while (!stop_token && soundtouch.available() > max_queued_samples) nae_fiber::this_fiber::yield();
-						float* samples = upload_as_f32(frame, d_raw, d_f32);
-						soundtouch.put(samples, frame->nb_samples);
-						gpu::wait(stop_token);  // d_raw / d_f32 are reused for the next frame
+						size_t total = 0;
+						float* samples = upload_as_f32(batch, d_raw, d_f32, &total);
+						soundtouch.put(samples, total);
+						gpu::wait(stop_token);  // d_raw / d_f32 are reused by the next batch; the frames are released
+						batch_stats.rounds += batch.size();
+						batch_stats.waits++;
 					}
 				}
 				if (soundtouch.open())
@@ -224,7 +268,7 @@ namespace processor
 	)
 	{
 		stretch_process_payload(input, output, stop_token, velocity, keep_pitch ? 1 / velocity : 1, get_processor_info().display_name,
-								algorithm);  // :452-459
+								algorithm, batch_stats);  // :452-459
 	}
 
 	Json::Value Velocity_modifier::serialize() const
@@ -258,7 +302,7 @@ namespace processor
 	)
 	{
 		stretch_process_payload(input, output, stop_token, 1, std::pow(2.0f, pitch / 12.0f), get_processor_info().display_name,
-								algorithm);  // :469-476
+								algorithm, batch_stats);  // :469-476
 	}
 
 	Json::Value Pitch_modifier::serialize() const
@@ -319,8 +363,9 @@ namespace processor
 				time_seconds = frame->pts * av_q2d(frame->time_base);
 				gpu::check(nae_spectrum_create(ctx, 1024, 256, ch, &spectrum), "nae_spectrum_create");
 			}
-			float* samples = upload_as_f32(frame, d_raw, d_f32);
-			gpu::check(nae_spectrum_put(spectrum, samples, frame->nb_samples), "nae_spectrum_put");
+			size_t total = 0;
+			float* samples = upload_as_f32({pop_result.value()}, d_raw, d_f32, &total);
+			gpu::check(nae_spectrum_put(spectrum, samples, total), "nae_spectrum_put");
 			const size_t ready = nae_spectrum_available(spectrum);
 			if (ready == 0) { gpu::wait(stop_token); continue; }
 			const size_t rec = (size_t)ch * 513;

@@ -26,6 +26,8 @@ namespace processor
 
 	  public:
 
+		Batch_stats batch_stats;  // of the last process_payload: frames put / waits for their uploads
+
 		static infra::Processor::Info get_processor_info();
 		Processor::Info get_processor_info_non_static() const override { return get_processor_info(); }
 		std::vector<infra::Processor::Pin_attribute> get_pin_attributes() const override;
@@ -45,6 +47,8 @@ namespace processor
 		Stretch_algorithm algorithm = default_stretch_algorithm();
 
 	  public:
+
+		Batch_stats batch_stats;  // of the last process_payload: frames put / waits for their uploads
 
 		static infra::Processor::Info get_processor_info();
 		Processor::Info get_processor_info_non_static() const override { return get_processor_info(); }

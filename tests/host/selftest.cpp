@@ -330,6 +330,9 @@ static void test_gpu_amix()
 	}
 	CHECK(pos >= (size_t)S, "all samples mixed (" << pos << ")");
 	CHECK(same, "amix output bit-exact vs oracle, planar, pts = cumulative end time");
+	// the sources fill their streams before the mixer's fiber runs: the waiting frames are mixed as batches behind one wait each
+	CHECK(mix->batch_stats.rounds >= sink->frames.size() && mix->batch_stats.waits * 2 <= mix->batch_stats.rounds,
+		  "amix batches the waiting frames: " << mix->batch_stats.rounds << " rounds behind " << mix->batch_stats.waits << " waits");
 }
 
 static void test_gpu_amix_converted_input()
@@ -435,6 +438,8 @@ static void test_gpu_pitch_spectrum_fanout()
 	}
 	CHECK(same, "spectrum frames bit-exact vs oracle on the same input");
 	for (auto& f : sink_audio->frames) CHECK(f->data()->nb_samples <= 3456, "chunks no larger than 3*1152/velocity (audio-velocity.cpp:417)");
+	CHECK(pitch->batch_stats.rounds == (size_t)(S + 1151) / 1152 && pitch->batch_stats.waits * 2 <= pitch->batch_stats.rounds,
+		  "pitch node puts the waiting frames as batches: " << pitch->batch_stats.rounds << " frames behind " << pitch->batch_stats.waits << " waits");
 }
 
 static void test_gpu_velocity_keep_pitch()
@@ -624,6 +629,8 @@ static void test_gpu_bimix_v1()
 	}
 	CHECK(pos == (size_t)S, "bimix delivered every sample: " << pos);
 	CHECK(same, "bimix output bit-exact vs the oracle (K4)");
+	CHECK(mix->batch_stats.waits * 2 <= mix->batch_stats.rounds,
+		  "bimix batches the waiting frames: " << mix->batch_stats.rounds << " rounds behind " << mix->batch_stats.waits << " waits");
 }
 
 int main(int argc, char** argv)

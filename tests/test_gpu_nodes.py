@@ -330,30 +330,71 @@ def test_n2_input_conversion(ctx, nae):
     assert lib.nae_swr_create(ctx.h, nae.FMT_FLT, 48000, 6, 48000, C.byref(h)) == -1
 
 
-def swr_drive(ctx, nae, fmt, in_rate, ch, planes_of, n_total, chunks, max_out=4096):
-    """swr_convert-style driving of nae_swr: put the chunks (receiving at most max_out frames per call), then drain"""
+def swr_drive(ctx, nae, fmt, in_rate, ch, planes_of, n_total, chunks, max_out=4096, queued=False):
+    """swr_convert-style driving of nae_swr: put the chunks (receiving at most max_out frames per call), then drain.
+    queued: through nae_swr_convert — device planes, nothing waited for until every call has been queued"""
     import ctypes as C
     lib = ctx.lib
     h, got = C.c_void_p(), C.c_size_t()
     assert lib.nae_swr_create(ctx.h, fmt, in_rate, ch, 48000, C.byref(h)) == 0
     outL, outR, pos, i = [], [], 0, 0
+    keep, dev = [], []          # host planes stay alive until the stream has been waited for
+
+    def call(planes, n):
+        if queued:
+            d = ctx.empty(2 * max_out, np.float32)
+            assert lib.nae_swr_convert(h, planes, n, d.ptr, d.ptr + 4 * max_out, max_out, C.byref(got)) == 0
+            dev.append((d, got.value))
+        else:
+            L, R = np.zeros(max_out, np.float32), np.zeros(max_out, np.float32)
+            assert lib.nae_swr_convert_host(h, planes, n, L.ctypes.data, R.ctypes.data, max_out, C.byref(got)) == 0
+            outL.append(L[: got.value].copy()); outR.append(R[: got.value].copy())
+        return got.value
+
     while pos < n_total:
         n = min(chunks[i % len(chunks)], n_total - pos)
         arrs = planes_of(pos, n)
-        planes = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
-        L, R = np.zeros(max_out, np.float32), np.zeros(max_out, np.float32)
-        assert lib.nae_swr_convert_host(h, planes, n, L.ctypes.data, R.ctypes.data, max_out, C.byref(got)) == 0
-        outL.append(L[: got.value].copy()); outR.append(R[: got.value].copy())
+        keep.append(arrs)
+        call((C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs]), n)
         pos += n
         i += 1
-    while True:
-        L, R = np.zeros(max_out, np.float32), np.zeros(max_out, np.float32)
-        assert lib.nae_swr_convert_host(h, None, 0, L.ctypes.data, R.ctypes.data, max_out, C.byref(got)) == 0
-        if got.value == 0:
-            break
-        outL.append(L[: got.value].copy()); outR.append(R[: got.value].copy())
+    while call(None, 0):
+        pass
+    if queued:
+        ctx.sync()
+        for d, n in dev:
+            both = d.download()
+            outL.append(both[:n].copy()); outR.append(both[max_out: max_out + n].copy())
     assert lib.nae_swr_destroy(h) == 0
     return np.concatenate(outL), np.concatenate(outR)
+
+
+@pytest.mark.parametrize("fmt_name,in_rate,ch", [("FLT", 44100, 2), ("S16P", 22050, 1), ("FLTP", 48000, 2), ("S32", 48000, 1)])
+def test_n2_queued_convert_equals_host_convert(ctx, nae, fmt_name, in_rate, ch):
+    """nae_swr_convert (device planes, no wait between calls: what the mixer nodes queue per waiting frame) delivers the
+    frames of nae_swr_convert_host bit for bit, call by call"""
+    rng = np.random.default_rng(77)
+    n = 9000
+    fmt = getattr(nae, "FMT_" + fmt_name)
+    planar = fmt_name.endswith("P")
+    if fmt_name.startswith("FLT"):
+        x = rng.uniform(-1, 1, (n, ch)).astype(np.float32)
+    elif fmt_name.startswith("S16"):
+        x = rng.integers(-32768, 32767, (n, ch)).astype(np.int16)
+    else:
+        x = rng.integers(-2**31, 2**31 - 1, (n, ch)).astype(np.int32)
+
+    def planes_of(p, k):
+        if planar:
+            return [np.ascontiguousarray(x[p: p + k, c]) for c in range(ch)]
+        return [np.ascontiguousarray(x[p: p + k].reshape(-1))]
+
+    chunks = [1152, 1152, 300, 2049]
+    a = swr_drive(ctx, nae, fmt, in_rate, ch, planes_of, n, chunks, max_out=1152)
+    b = swr_drive(ctx, nae, fmt, in_rate, ch, planes_of, n, chunks, max_out=1152, queued=True)
+    assert a[0].size == b[0].size and a[0].size > 0
+    assert_bits(b[0], a[0], f"{fmt_name} L")
+    assert_bits(b[1], a[1], f"{fmt_name} R")
 
 
 @pytest.mark.parametrize("in_rate", [44100, 22050, 96000, 8000])
