@@ -52,6 +52,19 @@ __device__ unsigned long long g_pipe_total[4 * 64];      // {cycles, realtime ti
 #define PIPE_BARRIER(t, which) pipe_barrier()
 #endif
 
+// Issue priority.  Two workgroups share a CU and the hardware arbitrates equal priorities by age: measured (tools/pipe_stamps.py)
+// the workgroup that arrived first runs a step in 4700 cycles, its neighbour in 7060, on every CU — the first finishes a
+// third earlier and the CU then runs half empty.  So the two take turns: a workgroup learns whether it was the first or the
+// second on its CU (g_cu_arrivals, counted per physical CU, never reset: only the parity is used) and raises its priority on
+// alternate steps (6.95-7.03 ms against 7.14-7.17 on one box; raising the role on a step's critical path as well — R1 between
+// barriers A and B, R3 between B and A — made it 7.4).
+__device__ unsigned g_cu_arrivals[8 * 4 * 16];
+__device__ __forceinline__ void pipe_prio(int t, int slot)
+{
+    if ((t + slot) & 1) __builtin_amdgcn_s_setprio(2);      // wave-uniform
+    else __builtin_amdgcn_s_setprio(0);
+}
+
 template <bool kUnit>
 __global__ __launch_bounds__(kPipeThreads, 6) void pv_pipe_kernel(SigViewD src, PvParams p, long long n_sc,
                                                                  const uint32_t* __restrict__ base_phase, OutViewD out, Tables tb)
@@ -65,7 +78,15 @@ __global__ __launch_bounds__(kPipeThreads, 6) void pv_pipe_kernel(SigViewD src, 
     for (int i = threadIdx.x; i < NAE_FFT_BINS; i += kPipeThreads) t1024[i] = tb.t1024[i];
     if (threadIdx.x < 64) w64[threadIdx.x] = tb.w512[8 * (threadIdx.x >> 3) * (threadIdx.x & 7)];
     fill_twa(twa, tb.w512, threadIdx.x, kPipeThreads);
+    __shared__ int s_slot;
+    if (threadIdx.x == 0) {
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);            // HW_ID: CU 8-11, SE 13-14
+        const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 7u;     // XCC_ID
+        const unsigned key = (xcc * 4 + ((hw >> 13) & 3u)) * 16 + ((hw >> 8) & 15u);
+        s_slot = (int)(atomicAdd(&g_cu_arrivals[key], 1u) & 1u);
+    }
     __syncthreads();
+    const int slot = __builtin_amdgcn_readfirstlane(s_slot);
 
     const int wave = wave_id();
     const int role = wave / kPipeSc, half = wave % kPipeSc;  // scalars
@@ -113,6 +134,7 @@ __global__ __launch_bounds__(kPipeThreads, 6) void pv_pipe_kernel(SigViewD src, 
 #pragma unroll 1
         for (int t = 0; t < n + 2; t++) {
             PIPE_BARRIER(t, 0);                               // A
+            pipe_prio(t, slot);
             if (t < n) {
                 // register-only part while R2 reads Z of frame t-1 out of this wave's scratch
 #pragma unroll
@@ -159,6 +181,7 @@ __global__ __launch_bounds__(kPipeThreads, 6) void pv_pipe_kernel(SigViewD src, 
             const bool active = (t >= 1) && (t <= n);
             const long long f = f_first + t - 1;
             PIPE_BARRIER(t, 0);                               // A: Z of frame f is complete
+            pipe_prio(t, slot);
             cf va[8], nyq{0.0f, 0.0f};
             if (active) {
                 cf vb[8];
@@ -239,6 +262,7 @@ __global__ __launch_bounds__(kPipeThreads, 6) void pv_pipe_kernel(SigViewD src, 
             const long long fz = f_first + t - 2;
             const bool active = (t >= 2) && (fz >= b0);
             PIPE_BARRIER(t, 0);                               // A: Y of frame fz is complete
+            pipe_prio(t, slot);
             cf zs[8];
             if (active) {
                 // c2r pre-twiddle into FFT input layout, conjugated (inverse = conj(FFT(conj Z)) / 512); 2E, 2D: see kGain

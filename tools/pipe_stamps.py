@@ -2,6 +2,7 @@
 """Diagnostic (variant build -DNAE_PIPE_STAMPS, never shipped): per-wave s_memtime stamps around the two barriers of eight
 steps of pv_pipe_kernel, workgroup 0, while the C5 graph runs.  Build: tools/mkvariant.sh stamps -DNAE_PIPE_STAMPS
 Run:   NAE_GPU_LIB=nodey-audio-editor_amd/variants/libnae_gpu_stamps.so python tools/pipe_stamps.py"""
+import collections
 import ctypes as C
 import os
 import sys
@@ -59,3 +60,11 @@ hw = tot[:, 3].astype(np.int64) & 0xffffffff
 for x in sorted(set(xcc.tolist())):
     m = xcc == x
     print(f"xcc {x}: {m.sum():2d} sampled workgroups, cycles/step " + " ".join(str(int(v)) for v in sorted((cyc / steps)[m])) + "  GHz %.2f" % np.median((cyc / real * 0.1)[m]))
+# which workgroups share a CU, and who is the fast one: HW_ID (gfx9) bits 8-11 = CU, 12 = SH, 13-14 = SE
+cu, sh, se = (hw >> 8) & 0xf, (hw >> 12) & 0x1, (hw >> 13) & 0x3
+place = collections.defaultdict(list)
+for j in range(64):
+    place[(int(xcc[j]), int(se[j]), int(sh[j]), int(cu[j]))].append((j, int(cyc[j] / steps[j])))
+print("workgroups by (xcc, se, sh, cu): [(dispatch index within the XCD, cycles per step), ...]")
+for k in sorted(place):
+    print("  ", k, place[k])
