@@ -137,11 +137,13 @@ __global__ __launch_bounds__(kPipeThreads, 6) void pv_pipe_kernel(SigViewD src, 
             pipe_prio(t, slot);
             if (t < n) {
                 // register-only part while R2 reads Z of frame t-1 out of this wave's scratch
+                // (all reads of a phase are requested before the first one is used: the accesses are volatile, so the compiler
+                // keeps them where they are written, and one read per product would cost one LDS round trip each)
+                cf w[8];
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const cf w = lds_ld(hw + 64 * j);
-                    va[j] = cf{nxt[j].x * w.x, nxt[j].y * w.y};
-                }
+                for (int j = 0; j < 8; j++) w[j] = lds_ld(hw + 64 * j);
+#pragma unroll
+                for (int j = 0; j < 8; j++) va[j] = cf{nxt[j].x * w[j].x, nxt[j].y * w[j].y};
                 fft512_pad_a(va, L);
             }
             PIPE_BARRIER(t, 1);                               // B: R2 holds X of frame t-1 in registers
@@ -196,12 +198,15 @@ __global__ __launch_bounds__(kPipeThreads, 6) void pv_pipe_kernel(SigViewD src, 
                     const cf P = cmul_tw(O, t1024[512]);
                     nyq = cf{E.x + P.y, E.y - P.x};
                 }
+                cf tw[8];
+#pragma unroll
+                for (int r = 0; r < 8; r++) tw[r] = lds_ld(tsp + 64 * r);
 #pragma unroll
                 for (int r = 0; r < 8; r++) {
                     const cf A = va[r], B = vb[r];
                     const cf E = cf{A.x + B.x, A.y - B.y};
                     const cf O = cf{A.x - B.x, A.y + B.y};
-                    const cf P = cmul_tw(O, lds_ld(tsp + 64 * r));
+                    const cf P = cmul_tw(O, tw[r]);
                     va[r] = cf{E.x + P.y, E.y - P.x};
                 }
             }
@@ -267,13 +272,22 @@ __global__ __launch_bounds__(kPipeThreads, 6) void pv_pipe_kernel(SigViewD src, 
             if (active) {
                 // c2r pre-twiddle into FFT input layout, conjugated (inverse = conj(FFT(conj Z)) / 512); 2E, 2D: see kGain
 #pragma unroll
-                for (int r = 0; r < 8; r++) {
-                    const cf Xk = lds_ld(Yn + 64 * r), Xm = lds_ld(Ym + 448 - 64 * r);
-                    const cf T = lds_ld(tsp + 64 * r);
-                    const cf E{Xk.x + Xm.x, Xk.y - Xm.y};
-                    const cf D{Xk.x - Xm.x, Xk.y + Xm.y};
-                    const cf Q{__builtin_fmaf(T.x, D.x, T.y * D.y), __builtin_fmaf(T.x, D.y, -(T.y * D.x))};
-                    zs[r] = cf{E.x - Q.y, -(E.y + Q.x)};
+                for (int h = 0; h < 2; h++) {
+                    cf Xk[4], Xm[4], T[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int r = 4 * h + q;
+                        Xk[q] = lds_ld(Yn + 64 * r);
+                        Xm[q] = lds_ld(Ym + 448 - 64 * r);
+                        T[q] = lds_ld(tsp + 64 * r);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const cf E{Xk[q].x + Xm[q].x, Xk[q].y - Xm[q].y};
+                        const cf D{Xk[q].x - Xm[q].x, Xk[q].y + Xm[q].y};
+                        const cf Q{__builtin_fmaf(T[q].x, D.x, T[q].y * D.y), __builtin_fmaf(T[q].x, D.y, -(T[q].y * D.x))};
+                        zs[4 * h + q] = cf{E.x - Q.y, -(E.y + Q.x)};
+                    }
                 }
             }
             PIPE_BARRIER(t, 1);                               // B: R2 may overwrite Y

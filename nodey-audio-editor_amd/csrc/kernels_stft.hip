@@ -80,14 +80,8 @@ __global__ __launch_bounds__(kThreads, 4) void spectrum_kernel(SigViewD src, lon
 // the loads of frame f and, older than them, only the stores of frame f-2.  The magnitudes of the previous frame ride along
 // in 18 registers.  (tools/ubench/spec_abl.hip, profiles/r02_spectrum_ablation.md: 3.43 -> 3.16 ms on the C5 signal; stores
 // that bypass L2 allocation — they are never read again by this kernel — another 0.1-0.3 ms.)
-#ifndef NAE_SPEC_CHUNK
-#define NAE_SPEC_CHUNK 32
-#endif
-constexpr int kSpecChunk = NAE_SPEC_CHUNK;
-#ifndef NAE_SPEC_STORE_AUX
-#define NAE_SPEC_STORE_AUX 2
-#endif
-constexpr int kSpecStoreAux = NAE_SPEC_STORE_AUX;       // cache policy bits of the spectrum stores (2 = nt)
+constexpr int kSpecChunk = 32;         // frames one wave walks (16 / 64 / 128 measured within 1 %: profiles/r02_spectrum_ablation.md)
+constexpr int kSpecStoreAux = 2;       // cache policy bits of the spectrum stores (2 = nt)
 constexpr size_t kLdsTablesPad = NAE_FFT_N * sizeof(float) + (kT1024Pad + 64 + kTwaCf) * sizeof(cf);
 constexpr size_t kLdsSpecStereo = kLdsTablesPad + kWaves * kPadScratchCf * sizeof(cf);
 
@@ -338,10 +332,8 @@ __global__ __launch_bounds__(256) void resample_kernel(SigViewD src, RsParams p,
 // tiled rate transposer: a 256-thread workgroup produces kRsOut consecutive output frames of one stream; the
 // source span it needs (kRsOut*rho + 16 samples per channel) is staged once into LDS with 16-byte loads, the
 // 16 taps are read from LDS, and interleaved stereo output leaves as one 8-byte store per frame.
-#ifndef NAE_RS_OUT
-#define NAE_RS_OUT 512      // measured: 256 -> 3.6 ms, 512 -> 3.07, 1024 -> 3.4 (C5 mix+transposer; LDS per workgroup sets the occupancy)
-#endif
-constexpr int kRsOut = NAE_RS_OUT;                     // output frames per workgroup
+constexpr int kRsOut = 512;                      // output frames per workgroup.  Measured: 256 -> 3.6 ms, 512 -> 3.07, 1024 -> 3.4
+                                                 // (C5 mix+transposer; LDS per workgroup sets the occupancy)
 constexpr int kRsRow = 20;                       // LDS row stride of the coefficient table (16 taps + 4 pad): a 64-B
                                                  // stride maps every row to one of 4 bank slots (4-way conflicts on b128)
 constexpr int kRsMaxSpan = 4096 + 32;            // staged source samples per channel (rho <= 4)
