@@ -51,6 +51,31 @@ def test_k8_stereo_batched_layouts_and_edges(ctx, nae):
     assert gpu_spectrum(ctx, nae, orc.fill_uniform(1024, 1), 1).shape == (1, 1, 1, 513)
 
 
+@pytest.mark.parametrize("planar", [False, True])
+def test_k8_non_finite_samples_stay_in_their_frames(ctx, nae, planar):
+    """one NaN and one Inf sample in the left channel: exactly the frames whose window covers them are non-finite (as in the
+    oracle), the right channel and every other frame stay bit-exact — the stereo kernel keeps 6 of a frame's 8 input rows in
+    registers for the next frame and walks 32 frames per wave, so a slip there would spread them"""
+    T = 1024 + 256 * 70 + 5
+    x = orc.fill_uniform(2 * T, 91).reshape(T, 2).copy()
+    bad = {3000: np.nan, 11111: np.inf}
+    for pos, v in bad.items():
+        x[pos, 0] = v
+    flat = np.ascontiguousarray(x.T).reshape(-1) if planar else x.reshape(-1)
+    got = gpu_spectrum(ctx, nae, flat, 2, planar=planar)[0]
+    ref = orc.spectrum(x.reshape(-1), 2)
+    F = got.shape[0]
+    touched = np.zeros(F, bool)
+    for pos in bad:
+        for f in range(F):
+            touched[f] |= 256 * f <= pos < 256 * f + 1024
+    assert touched.sum() == 8
+    assert np.array_equal(got[:, 1].view(np.uint32), ref[:, 1].view(np.uint32)), "right channel"
+    assert np.array_equal(got[~touched, 0].view(np.uint32), ref[~touched, 0].view(np.uint32)), "clean frames of the left channel"
+    assert not np.isfinite(got[touched, 0]).any() and not np.isfinite(ref[touched, 0]).any()
+    assert np.isfinite(got[~touched]).all()
+
+
 def test_k8_linearity_at_full_size(ctx, nae):
     """size-independent property at the C5 per-stream size (10 s): spectrum(2x) == 2*spectrum(x), bit-exact"""
     T = 480000
@@ -153,6 +178,28 @@ def test_k7_against_the_specification_golden(ctx, nae, golden, name):
     got, _ = gpu_stretch(ctx, nae, g[str(g[name + "_src"])], int(ch), float(rate), float(pitch))
     assert got.size == g[name].size
     assert rel_rms(got, g[name]) <= TOL
+
+
+def test_k7_non_finite_sample_is_confined(ctx, nae):
+    """a NaN sample in one channel: the output is non-finite only where the oracle's is (the frames whose window covers it,
+    after the transposer), the other channel and the rest of the stream stay within tolerance — phases of the poisoned frames are
+    0 on both sides (atan2 of a non-positive maximum), so the recurrence carries on identically"""
+    L, ch, pitch = 60000, 2, 2 ** (3 / 12)
+    x = (0.5 * orc.fill_uniform(L * ch, 43)).reshape(L, ch).copy()
+    x[30001, 0] = np.nan
+    got = gpu_stretch(ctx, nae, x.reshape(-1), ch, 1.0, pitch)[0].reshape(-1, ch)
+    ref = orc.stretch(x.reshape(-1), ch, 1.0, pitch).reshape(-1, ch)
+    assert got.shape == ref.shape
+    bad_ref, bad_got = ~np.isfinite(ref), ~np.isfinite(got)
+    assert not bad_ref[:, 1].any() and not bad_got[:, 1].any(), "the clean channel stays finite"
+    assert 1000 < bad_ref[:, 0].sum() < 4000
+    # same poisoned span up to the transposer's 16-tap reach at its edges
+    lo, hi = np.flatnonzero(bad_ref[:, 0])[[0, -1]]
+    glo, ghi = np.flatnonzero(bad_got[:, 0])[[0, -1]]
+    assert abs(int(lo) - int(glo)) <= 16 and abs(int(hi) - int(ghi)) <= 16, (lo, hi, glo, ghi)
+    ok = np.ones(ref.shape[0], bool)
+    ok[min(lo, glo) - 16: max(hi, ghi) + 17] = False
+    assert rel_rms(got[ok], ref[ok]) <= TOL, rel_rms(got[ok], ref[ok])
 
 
 def test_k7_batched_streams_are_independent(ctx, nae):
