@@ -487,47 +487,104 @@ namespace processor
 		};
 		Side side[2] = {Side(in_l.value().get()), Side(in_r.value().get())};
 
-		// take one frame off an input: convert, advance the side's clock by what the converter delivered (:594-618: a block is
-		// stamped with the time BEHIND it), mix it down to mono on the GPU and queue it
+		// Batching as in the other mixers: everything that is waiting is queued on the GPU and waited for once — on the intake side
+		// every frame already in an input stream (conversion, mono mix-down and download per frame, one wait per side and round),
+		// on the output side every frame the alignment loop can form from the queued blocks (upload, interleave, download per
+		// frame, one wait per round).
+		constexpr size_t max_batch = 16;
+		batch_stats = {};
+
+		// take the waiting frames off an input: convert, advance the side's clock by what the converter delivered (:594-618: a
+		// block is stamped with the time BEHIND it), mix down to mono on the GPU and queue the blocks
+		gpu::Device_buffer d_l, d_r, d_m;
 		auto intake = [&](Side& sd)
 		{
 			if (sd.ended) return;
-			const auto popped = sd.stream.try_pop();
-			if (!popped.has_value())
+			std::vector<std::shared_ptr<const Audio_frame>> frames;
+			while (frames.size() < max_batch)
 			{
-				if (popped.error() == channel_op_status::empty && sd.stream.eof()) sd.ended = true;
-				return;
+				const auto popped = sd.stream.try_pop();
+				if (!popped.has_value())
+				{
+					if (popped.error() == channel_op_status::empty && sd.stream.eof()) sd.ended = frames.empty();
+					break;
+				}
+				frames.push_back(popped.value());
 			}
-			const auto& data = *popped.value()->data();
-			if (data.ch_layout.nb_channels != 2 && data.ch_layout.nb_channels != 1)
-				throw Runtime_error("Invalid audio channel layout", "Audio channel layout must be stereo or mono.",
-									infra::fmt("Invalid channel layout: %d", data.ch_layout.nb_channels));
-			if (!sd.opened)
+			if (frames.empty()) return;
+			size_t room_total = 0;
+			for (const auto& f : frames)
 			{
-				sd.opened = true;
-				sd.resampler.open(data);
-				sd.clock = data.pts * av_q2d(data.time_base);
+				const auto& data = *f->data();
+				if (data.ch_layout.nb_channels != 2 && data.ch_layout.nb_channels != 1)
+					throw Runtime_error("Invalid audio channel layout", "Audio channel layout must be stereo or mono.",
+										infra::fmt("Invalid channel layout: %d", data.ch_layout.nb_channels));
+				room_total += (2 * (size_t)data.nb_samples + 3) / 4 * 4;
 			}
-			const size_t room = 2 * (size_t)data.nb_samples;
-			std::vector<float> l(room + 1, 0.0f), r(room + 1, 0.0f);
-			const int n = sd.resampler.convert(&data, l.data(), r.data(), (int)room);
-			sd.clock += double(n) / rate;
-			if (n == 0) return;
-			Pending block;
-			block.begin = sd.clock;
-			block.mono.resize(n);
-			float* da = static_cast<float*>(d_a.reserve(n * sizeof(float)));
-			float* db = static_cast<float*>(d_b.reserve(n * sizeof(float)));
-			float* dm = static_cast<float*>(d_out.reserve(2 * n * sizeof(float) + 64));
-			gpu::check(nae_memcpy_h2d(ctx, da, l.data(), n * sizeof(float)), "h2d");
-			gpu::check(nae_memcpy_h2d(ctx, db, r.data(), n * sizeof(float)), "h2d");
-			gpu::check(nae_bimix2_downmix_f32(ctx, da, db, dm, n), "nae_bimix2_downmix_f32");
-			gpu::check(nae_memcpy_d2h(ctx, block.mono.data(), dm, n * sizeof(float)), "d2h");
-			gpu::wait(stop_token);
-			sd.queue.emplace_back(std::move(block));
+			float* dl = static_cast<float*>(d_l.reserve(room_total * sizeof(float)));
+			float* dr = static_cast<float*>(d_r.reserve(room_total * sizeof(float)));
+			float* dm = static_cast<float*>(d_m.reserve(room_total * sizeof(float)));
+			std::vector<Pending> staged;
+			staged.reserve(frames.size());  // the downloads below write into the blocks' vectors: they must not move
+			size_t off = 0;
+			for (const auto& f : frames)
+			{
+				const auto& data = *f->data();
+				if (!sd.opened)
+				{
+					sd.opened = true;
+					sd.resampler.open(data);
+					sd.clock = data.pts * av_q2d(data.time_base);
+				}
+				const size_t room = 2 * (size_t)data.nb_samples;
+				const int n = sd.resampler.convert_queued(&data, dl + off, dr + off, (int)room);
+				sd.clock += double(n) / rate;
+				if (n > 0)
+				{
+					Pending block;
+					block.begin = sd.clock;
+					block.mono.resize(n);
+					gpu::check(nae_bimix2_downmix_f32(ctx, dl + off, dr + off, dm + off, n), "nae_bimix2_downmix_f32");
+					staged.emplace_back(std::move(block));
+					gpu::check(nae_memcpy_d2h(ctx, staged.back().mono.data(), dm + off, n * sizeof(float)), "d2h");
+				}
+				off += (room + 3) / 4 * 4;
+			}
+			gpu::wait(stop_token);  // the frames (upload sources) are released only now
+			batch_stats.rounds += frames.size();
+			batch_stats.waits++;
+			for (Pending& block : staged) sd.queue.emplace_back(std::move(block));
 		};
 
-		// one output frame: `solo` samples of side `first` alone, then `both` samples of the two sides
+		// output frames queued on the GPU since the last flush; the blocks their uploads read from stay alive in `retired`
+		struct Job { std::shared_ptr<Audio_frame> frame; };
+		std::vector<Job> jobs;
+		std::vector<Pending> retired;
+		size_t job_floats_a = 0, job_floats_b = 0, job_floats_out = 0, round_cap = 0;
+		auto flush = [&]()
+		{
+			if (jobs.empty()) { retired.clear(); return; }
+			gpu::wait(stop_token);
+			batch_stats.rounds += jobs.size();
+			batch_stats.waits++;
+			for (Job& j : jobs) push_to_all(output_stream, j.frame, stop_token);
+			jobs.clear();
+			retired.clear();
+			job_floats_a = job_floats_b = job_floats_out = 0;
+		};
+		// capacity for one round of output frames: every pending sample is played at most once per side
+		auto reserve_round = [&]()
+		{
+			size_t pending = 64;
+			for (const Side& sd : side)
+				for (const Pending& q : sd.queue) pending += (q.span().count + 3) / 4 * 4 + 4;
+			d_a.reserve(pending * sizeof(float));
+			d_b.reserve(pending * sizeof(float));
+			d_out.reserve(2 * pending * sizeof(float) + 64);
+			round_cap = pending;
+		};
+
+		// one output frame: `solo` samples of side `first` alone, then `both` samples of the two sides (queued, not waited for)
 		auto emit = [&](const float* first_side, const float* other_side, size_t solo, size_t both, int first, double begin)
 		{
 			const size_t n = solo + both;
@@ -542,22 +599,27 @@ namespace processor
 			frame_get_buffer(data, 32);
 			if (n)
 			{
-				float* da = static_cast<float*>(d_a.reserve(n * sizeof(float)));
-				float* db = static_cast<float*>(d_b.reserve((both ? both : 1) * sizeof(float)));
-				float* dd = static_cast<float*>(d_out.reserve(2 * n * sizeof(float) + 64));
+				float* da = d_a.as<float>() + job_floats_a;
+				float* db = d_b.as<float>() + job_floats_b;
+				float* dd = d_out.as<float>() + job_floats_out;
 				gpu::check(nae_memcpy_h2d(ctx, da, first_side, n * sizeof(float)), "h2d");
 				if (both) gpu::check(nae_memcpy_h2d(ctx, db, other_side, both * sizeof(float)), "h2d");
 				gpu::check(nae_bimix2_interleave_f32(ctx, dd, da, both ? db : nullptr, solo, both, first), "nae_bimix2_interleave_f32");
 				gpu::check(nae_memcpy_d2h(ctx, data->data[0], dd, 2 * n * sizeof(float)), "d2h");
-				gpu::wait(stop_token);
+				job_floats_a += (n + 3) / 4 * 4;
+				job_floats_b += (both + 3) / 4 * 4;
+				job_floats_out += (2 * n + 3) / 4 * 4;
 			}
-			push_to_all(output_stream, frame, stop_token);
+			jobs.push_back({frame});
 		};
 		auto emit_alone = [&](int which)
 		{
+			reserve_round();
 			Pending& p = side[which].queue.front();
 			emit(p.data(), nullptr, p.span().count, 0, which, p.begin);
+			retired.emplace_back(std::move(p));
 			side[which].queue.pop_front();
+			flush();
 		};
 
 		while (!stop_token)
@@ -570,26 +632,29 @@ namespace processor
 			// one input has ended and is drained: the other plays on alone, block by block
 			if (idle[1] && side[1].ended) { if (!idle[0]) emit_alone(0); continue; }
 			if (idle[0] && side[0].ended) { if (!idle[1]) emit_alone(1); continue; }
+			reserve_round();
 			while (!side[0].queue.empty() && !side[1].queue.empty() && !stop_token)
 			{
 				Pending* p[2] = {&side[0].queue.front(), &side[1].queue.front()};
+				// (a frame takes at most both blocks' samples: if the staging buffers could not hold it, what is queued goes out first)
+				if (job_floats_a + p[0]->span().count + p[1]->span().count + 16 > round_cap) flush();
 				const bimix::Step st = bimix::align_step(p[0]->span(), p[1]->span(), rate);
 				const int a = st.first, b = 1 - st.first;
 				const float* fa = p[a]->data();
 				const float* fb = p[b]->data();
 				const double begin = p[a]->begin;
 				// the queues change before the frame is built: its sample pointers stay valid (a deque keeps the blocks it does not
-				// remove in place, and the removed ones are moved out first)
-				Pending keep[2];
+				// remove in place, and the removed ones are moved to `retired`, which lives until the uploads have been waited for)
 				for (int k = 0; k < 2; k++)
 				{
-					if (st.used_up[k]) { keep[k] = std::move(*p[k]); side[k].queue.pop_front(); }
+					if (st.used_up[k]) { retired.emplace_back(std::move(*p[k])); side[k].queue.pop_front(); }
 					else p[k]->play(st.played[k]);
 				}
 				for (int k = 0; k < 2; k++)
-					if (!st.used_up[k] && p[k]->span().count == 0) { keep[k] = std::move(*p[k]); side[k].queue.pop_front(); }
+					if (!st.used_up[k] && p[k]->span().count == 0) { retired.emplace_back(std::move(*p[k])); side[k].queue.pop_front(); }
 				emit(fa, fb, st.solo, st.both, a, begin);
 			}
+			flush();
 		}
 		for (auto& stream : output_stream) stream->set_eof();
 	}

@@ -59,6 +59,8 @@ namespace processor
 	{
 	  public:
 
+		Batch_stats batch_stats;  // of the last process_payload: input frames taken + output frames built / waits
+
 		static infra::Processor::Info get_processor_info();
 		Processor::Info get_processor_info_non_static() const override { return get_processor_info(); }
 		std::vector<infra::Processor::Pin_attribute> get_pin_attributes() const override;

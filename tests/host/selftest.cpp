@@ -536,6 +536,8 @@ static void test_gpu_bimix_v2()
 	CHECK(il == (size_t)S, "left side complete: " << il);
 	CHECK(ir + 2 >= (size_t)S, "right side complete up to the rounding slack the reference allows (audio-bimix.cpp:826): " << ir);
 	CHECK(lead >= 478 && lead <= 482, "right channel starts ~480 frames late: " << lead);
+	CHECK(mix->batch_stats.waits * 2 <= mix->batch_stats.rounds,
+		  "bimix_v2 batches its intake and its output frames: " << mix->batch_stats.rounds << " frames behind " << mix->batch_stats.waits << " waits");
 }
 
 // velocity_modifier / pitch_modifier nodes without an "algorithm" key (projects saved by the reference) follow the default the
