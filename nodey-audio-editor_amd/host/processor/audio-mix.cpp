@@ -256,7 +256,7 @@ namespace processor
 
 			float* di = static_cast<float*>(d_in.reserve(in_floats * sizeof(float)));
 			float* dout = static_cast<float*>(d_out.reserve(out_floats * sizeof(float)));
-			gpu::check(nae_memset(ctx, di, 0, in_floats * sizeof(float)), "nae_memset");  // zero-filled planes [round][i][2][S]
+			if (in_floats) gpu::check(nae_memset(ctx, di, 0, in_floats * sizeof(float)), "nae_memset");  // zero-filled planes [round][i][2][S]
 			size_t done = 0;
 			for (Round& r : rounds)
 			{
@@ -403,7 +403,7 @@ namespace processor
 			}
 			float* di = static_cast<float*>(d_in.reserve(in_floats * sizeof(float)));
 			float* dout = static_cast<float*>(d_out.reserve(out_floats * sizeof(float)));
-			gpu::check(nae_memset(ctx, di, 0, in_floats * sizeof(float)), "nae_memset");
+			if (in_floats) gpu::check(nae_memset(ctx, di, 0, in_floats * sizeof(float)), "nae_memset");
 			size_t done = 0;
 			for (Round& r : rounds)
 			{
