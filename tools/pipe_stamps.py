@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic (variant build -DNAE_PIPE_STAMPS, never shipped): per-wave s_memtime stamps around the two barriers of eight
 steps of pv_pipe_kernel, workgroup 0, while the C5 graph runs.  Build: tools/mkvariant.sh stamps -DNAE_PIPE_STAMPS
-Run:   NAE_GPU_LIB=nodey-audio-editor_amd/variants/libnae_gpu_stamps.so python tools/pipe_stamps.py"""
+Run:   NAE_GPU_LIB=nodey-audio-editor_amd/variants/libnae_gpu_stamps.so python tools/pipe_stamps.py [n_streams]   (512: one workgroup per CU)"""
 import collections
 import ctypes as C
 import os
@@ -14,7 +14,7 @@ import naeload
 
 nae = naeload.load()
 ctx = nae.Context(0)
-n_streams, S, p = 1024, 480000, 2 ** (3 / 12)
+n_streams, S, p = (int(sys.argv[1]) if len(sys.argv) > 1 else 1024), 480000, 2 ** (3 / 12)
 pl = ctx.stretch_plan(1.0, p, S)
 F = ctx.spectrum_frames(pl.out_len)
 d_a, d_b = ctx.empty(n_streams * S * 2), ctx.empty(S * 2)
