@@ -52,6 +52,7 @@ print("cycles per step per wave:", np.round(per_step).astype(int))
 tot = np.zeros(4 * 64, np.uint64)
 assert ctx.lib.nae_debug_read_pipe_total(tot.ctypes.data_as(C.c_void_p)) == 0
 tot = tot.reshape(64, 4)
+tot = tot[tot[:, 2] > 0]                 # fewer than 64 workgroups on the sampled XCD (small batches)
 cyc, real, steps = tot[:, 0].astype(np.float64), tot[:, 1].astype(np.float64), tot[:, 2].astype(np.float64)
 print("whole loop, R1 wave of 64 sampled workgroups: cycles per step min/median/max =", int((cyc / steps).min()), int(np.median(cyc / steps)), int((cyc / steps).max()),
       "| clock GHz min/median/max = %.2f %.2f %.2f" % tuple(np.percentile(cyc / real * 0.1, [0, 50, 100])), "| loop ms median = %.3f" % (np.median(real) * 1e-5))
@@ -63,7 +64,7 @@ for x in sorted(set(xcc.tolist())):
 # which workgroups share a CU, and who is the fast one: HW_ID (gfx9) bits 8-11 = CU, 12 = SH, 13-14 = SE
 cu, sh, se = (hw >> 8) & 0xf, (hw >> 12) & 0x1, (hw >> 13) & 0x3
 place = collections.defaultdict(list)
-for j in range(64):
+for j in range(len(tot)):
     place[(int(xcc[j]), int(se[j]), int(sh[j]), int(cu[j]))].append((j, int(cyc[j] / steps[j])))
 print("workgroups by (xcc, se, sh, cu): [(dispatch index within the XCD, cycles per step), ...]")
 for k in sorted(place):
