@@ -80,13 +80,14 @@ __global__ __launch_bounds__(kThreads, 4) void spectrum_kernel(SigViewD src, lon
 // the loads of frame f and, older than them, only the stores of frame f-2.  The magnitudes of the previous frame ride along
 // in 18 registers.  (tools/ubench/spec_abl.hip, profiles/r02_spectrum_ablation.md: 3.43 -> 3.16 ms on the C5 signal; stores
 // that bypass L2 allocation — they are never read again by this kernel — another 0.1-0.3 ms.)
-constexpr int kSpecChunk = 32;         // frames one wave walks (16 / 64 / 128 measured within 1 %: profiles/r02_spectrum_ablation.md)
+constexpr int kSpecChunk = 32;         // frames one wave walks when the launch has many rounds of waves (16 / 64 / 128 measured
+                                       // within 1 %: profiles/r02_spectrum_ablation.md); small batches: spec_pick_chunk
 constexpr int kSpecStoreAux = 2;       // cache policy bits of the spectrum stores (2 = nt)
 constexpr size_t kLdsTablesPad = NAE_FFT_N * sizeof(float) + (kT1024Pad + 64 + kTwaCf) * sizeof(cf);
 constexpr size_t kLdsSpecStereo = kLdsTablesPad + kWaves * kPadScratchCf * sizeof(cf);
 
 __global__ __launch_bounds__(kThreads, 4) void spectrum_stereo_kernel(const float* __restrict__ src, long long src_ss, long long n_frames,
-                                                                     long long chunks_per_stream, long long n_items,
+                                                                     long long chunks_per_stream, int chunk, long long n_items,
                                                                      float* __restrict__ dst, long long dst_ss, Tables tb)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -108,8 +109,8 @@ __global__ __launch_bounds__(kThreads, 4) void spectrum_stereo_kernel(const floa
     const cf* tsp = t1024 + lane;
     // (the 64-bit divisions run on the vector ALU: bring the wave-uniform results back to scalar registers)
     const int s = __builtin_amdgcn_readfirstlane((int)(item / chunks_per_stream));
-    const int f0 = __builtin_amdgcn_readfirstlane((int)(item % chunks_per_stream)) * kSpecChunk;
-    const int f1 = f0 + kSpecChunk > (int)n_frames ? (int)n_frames : f0 + kSpecChunk;
+    const int f0 = __builtin_amdgcn_readfirstlane((int)(item % chunks_per_stream)) * chunk;
+    const int f1 = f0 + chunk > (int)n_frames ? (int)n_frames : f0 + chunk;
     const float* sbase = src + (long long)s * src_ss + 4 * lane;   // frames lie fully inside [0, T) by construction
     float* obase = dst + (long long)s * dst_ss;
     float ma[9], mb[9];
@@ -634,6 +635,28 @@ static int rs_pick_rot(unsigned long long step_q32)
     return best;
 }
 
+// frames per wave of the stereo spectrum kernel.  A CU holds 16 of its waves; with many rounds of waves the tail of the last
+// round does not matter and 32 frames keep the waves short.  A small batch (an eighth of the C5 job is 1.8 rounds at 32) gets
+// the chunk that fills a whole number of rounds: waves <= rounds x slots, the fewest frames per slot over the launch.
+static int spec_pick_chunk(long long frames, long long n_streams, int n_cu)
+{
+    const long long slots = (long long)n_cu * 16;
+    const long long waves32 = ((frames + kSpecChunk - 1) / kSpecChunk) * n_streams;
+    if (waves32 >= 8 * slots || n_streams > slots) return kSpecChunk;
+    long long best_chunk = kSpecChunk, best_cost = ((waves32 + slots - 1) / slots) * kSpecChunk;
+    for (long long rounds = 1; rounds <= 8; rounds++) {
+        const long long per_stream = rounds * slots / n_streams;            // chunks a stream may be cut into
+        if (per_stream < 1) continue;
+        long long chunk = (frames + per_stream - 1) / per_stream;
+        if (chunk < 8) chunk = 8;
+        if (chunk > 128) continue;                                           // (longer waves were not measured)
+        const long long waves = ((frames + chunk - 1) / chunk) * n_streams;
+        const long long cost = ((waves + slots - 1) / slots) * chunk;       // frames a slot walks over the launch
+        if (cost < best_cost) { best_cost = cost; best_chunk = chunk; }
+    }
+    return (int)best_chunk;
+}
+
 static inline SigViewD to_view(const nae_sig* s)
 {
     return SigViewD{static_cast<const float*>(s->base), (long long)s->stream_stride, (long long)s->chan_stride,
@@ -657,11 +680,12 @@ int nae_launch_spectrum(nae_ctx* ctx, const nae_sig* src, size_t T, int ch, size
     const bool stereo_fast = ch == 2 && src->chan_stride == 1 && src->frame_stride == 2 && src->stream_stride % 4 == 0 &&
                              (reinterpret_cast<uintptr_t>(src->base) & 15) == 0 && !ctx->dbg_spec_generic;
     if (stereo_fast) {
-        const long long chunks = ((long long)F + kSpecChunk - 1) / kSpecChunk;
+        const int chunk = spec_pick_chunk((long long)F, (long long)n_streams, ctx->n_cu);
+        const long long chunks = ((long long)F + chunk - 1) / chunk;
         const long long citems = chunks * (long long)n_streams;
         NAE_KLAUNCH(ctx, "spectrum_kernel", spectrum_stereo_kernel, dim3((unsigned)((citems + kWaves - 1) / kWaves)), dim3(kThreads),
                     kLdsSpecStereo, ctx->stream, static_cast<const float*>(src->base), (long long)src->stream_stride,
-                    (long long)F, chunks, citems, dst, (long long)dst_stream_stride, tb);
+                    (long long)F, chunks, chunk, citems, dst, (long long)dst_stream_stride, tb);
     }
     else if (src->frame_stride == 1)
         NAE_KLAUNCH(ctx, "spectrum_kernel", (spectrum_kernel<true>), dim3(grid), dim3(kThreads), lds, ctx->stream, to_view(src),

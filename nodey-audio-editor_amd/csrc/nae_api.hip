@@ -198,7 +198,10 @@ int nae_ctx_create(int device, nae_ctx** out)
     if (!ctx) return NAE_ERR_NOMEM;
     ctx->device = device;
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess) snprintf(ctx->name, sizeof ctx->name, "%s (%s)", prop.name, prop.gcnArchName);
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+        snprintf(ctx->name, sizeof ctx->name, "%s (%s)", prop.name, prop.gcnArchName);
+        if (prop.multiProcessorCount > 0) ctx->n_cu = prop.multiProcessorCount;
+    }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return NAE_ERR_HIP; }
     ctx->own_stream = true;
     if (const char* t = getenv("NAE_PV_TILE")) ctx->pv_tile = atoi(t) > 0 ? atoi(t) : 0;   // tuning knob (0 = automatic)

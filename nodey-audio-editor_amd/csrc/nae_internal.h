@@ -15,6 +15,7 @@ struct nae_ctx {
     bool own_stream = false;
     char err[512] = {0};
     char name[256] = {0};
+    int n_cu = 256;              // compute units of the device (launch-shape decisions)
     // read-only tables (built on the host in double, rounded once to f32)
     nae::cf* d_w512 = nullptr;   // exp(-2 pi i k/512),  k = 0..511
     nae::cf* d_t1024 = nullptr;  // exp(-2 pi i k/1024), k = 0..512
