@@ -2,11 +2,11 @@
 """Randomised differential run (GPU box): nae_stretch_block_f32 and nae_spectrum_block_f32 against the CPU oracle over random
 rates, pitches, lengths, channel counts, layouts and batch sizes — in particular batches around the vocoder's tile-policy
 thresholds (stream-channels 256 / 512 / 1024), where a stream is cut into 1, 2 or several time tiles.
-    python tools/fuzz_stretch.py [cases=40] [seed=1]"""
+    python tests/tools/fuzz_stretch.py [cases=40] [seed=1]"""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
@@ -19,11 +19,12 @@ def rel_rms(a, b):
     return d / max(np.sqrt(np.mean(b.astype(np.float64) ** 2)), 1e-30)
 
 
-def main():
-    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-    nae = naeload.load()
-    ctx = nae.Context(0)
+def main(cases=40, seed=1, ctx=None, nae=None):
+    rng = np.random.default_rng(seed)
+    if nae is None:
+        nae = naeload.load()
+    if ctx is None:
+        ctx = nae.Context(0)
     worst = 0.0
     for k in range(cases):
         ch = int(rng.choice([1, 2]))
@@ -68,7 +69,8 @@ def main():
                 assert np.array_equal(sp[s].view(np.uint32), ref.view(np.uint32)), f"spectrum differs: case {k} stream {s}"
     print(f"worst rel-RMS {worst:.2e} over {cases} cases (tolerance 1e-4)")
     assert worst <= 1e-4
+    return worst
 
 
 if __name__ == "__main__":
-    main()
+    main(*(int(a) for a in sys.argv[1:3]))

@@ -2,11 +2,11 @@
 """Randomised differential run (GPU box): the N2 input converter (nae_swr: swr-default polyphase resampler, format conversion,
 mono -> stereo) against oracle/orc_swr.c, bit for bit, over random input rates, formats, lengths and cuts into convert calls —
 through nae_swr_convert_host and through the queued nae_swr_convert.
-    python tools/fuzz_swr.py [cases=24] [seed=1]"""
+    python tests/tools/fuzz_swr.py [cases=24] [seed=1]"""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
@@ -15,11 +15,12 @@ import orc
 from test_gpu_nodes import swr_drive
 
 
-def main():
-    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-    nae = naeload.load()
-    ctx = nae.Context(0)
+def main(cases=24, seed=1, ctx=None, nae=None):
+    rng = np.random.default_rng(seed)
+    if nae is None:
+        nae = naeload.load()
+    if ctx is None:
+        ctx = nae.Context(0)
     done = 0
     for k in range(cases):
         in_rate = int(rng.choice([8000, 11025, 12000, 16000, 22050, 24000, 32000, 44100, 48000, 88200, 96000, 176400, 192000, int(rng.integers(7000, 200000))]))
@@ -44,7 +45,8 @@ def main():
         done += 1
         print(f"case {k:3d}: in_rate {in_rate:6d} frames {n:6d} -> {L.size:6d} chunks {chunks[:3]} max_out {max_out} {'queued' if queued else 'host'}  bit-exact", flush=True)
     print(f"{done} cases bit-exact")
+    return done
 
 
 if __name__ == "__main__":
-    main()
+    main(*(int(a) for a in sys.argv[1:3]))

@@ -2,11 +2,11 @@
 """Randomised differential run (GPU box): nae_wsola_block_f32 against oracle/orc_wsola.c — samples AND chosen overlap offsets,
 bit for bit — over random sample rates, rate / pitch settings, lengths, channel counts, layouts and batch sizes (640 streams
 is where the search switches from 2 to 4 candidates per thread and starts keeping the next window from the copied frames).
-    python tools/fuzz_wsola.py [cases=30] [seed=1]"""
+    python tests/tools/fuzz_wsola.py [cases=30] [seed=1]"""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
@@ -14,11 +14,12 @@ import naeload
 import orc
 
 
-def main():
-    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-    nae = naeload.load()
-    ctx = nae.Context(0)
+def main(cases=30, seed=1, ctx=None, nae=None):
+    rng = np.random.default_rng(seed)
+    if nae is None:
+        nae = naeload.load()
+    if ctx is None:
+        ctx = nae.Context(0)
     done = 0
     for k in range(cases):
         sr = int(rng.choice([8000, 16000, 22050, 32000, 44100, 48000]))
@@ -62,7 +63,8 @@ def main():
         print(f"case {k:3d}: sr {sr:5d} streams {n_streams:3d} ch {ch} L {L:6d} rate {rate:.3f} pitch {pitch:.3f} {kind:13s} "
               f"{'planar' if planar else 'interl'}  sequences {int(pl.n_seq):3d}  bit-exact", flush=True)
     print(f"{done} cases bit-exact (samples and offsets)")
+    return done
 
 
 if __name__ == "__main__":
-    main()
+    main(*(int(a) for a in sys.argv[1:3]))
