@@ -19,8 +19,18 @@
 #define NAE_HOP 256             /* synthesis hop / spectrum hop (N/4)      */
 #define NAE_OLA_GAIN (2.0f / 3.0f) /* 1 / sum_t hann^2 at hop N/4 = 1/1.5  */
 
-/* atan2 in turns: atan(t)/(2 pi) = t * Q(t*t), t in [0,1]; degree-6 minimax, max err 5.5e-8 turn.
- * Horner with fused multiply-add, coefficient order c0 (constant) .. c6.                                   */
+/* atan2 -> Q0.32 turns (revision 2 of the K7 / phase specification).  Every step is an IEEE f32 add / mul /
+ * fma or a two's-complement integer operation, so C and the GPU give the same 32 bits — and none of them is a division:
+ *   ax = |re|, ay = |im|,  mx = max(ax, ay, NAE_ATAN_TINY),  mn = min(ax, ay)
+ *   r  = bits_to_float(NAE_RCP_MAGIC - float_to_bits(mx));   three times:  e = fma(-mx, r, 1),  r = fma(r, e, r)
+ *   t  = mn * r,  s = t * t,  p = t * Q(s)      Q = Horner with fma over c6 .. c0, coefficients pre-scaled by 2^32:
+ *                                               atan(t)/(2 pi) = t * Q(s) / 2^32, degree-6 minimax, max err 5.5e-8 turn
+ *   i  = (int32) rint(p)                        first octant, 0 .. 2^29
+ *   ay > ax:        i = 0x40000000 - i          (1/4 turn - angle)
+ *   sign bit of re: i = 0x80000000 - i          (1/2 turn - angle;  wraps: +1/2 and -1/2 turn are the same phase)
+ *   sign bit of im: i = -i
+ * The octants follow the SIGN BITS (atan2(+0, -0) is half a turn, as in C); a vanishing bin (mx < 2^-100) has t = 0; a bin
+ * whose |re| + |im| is not finite (NaN, Inf, or the sum overflows) has phase 0.  Accurate for 2^-100 <= mx <= 2^100.           */
 #define NAE_ATAN_C0 1.591543257e-01f
 #define NAE_ATAN_C1 -5.302623659e-02f
 #define NAE_ATAN_C2 3.152511641e-02f
@@ -28,6 +38,9 @@
 #define NAE_ATAN_C4 1.267249603e-02f
 #define NAE_ATAN_C5 -5.348273553e-03f
 #define NAE_ATAN_C6 1.084129326e-03f
+#define NAE_ATAN_SCALE 4294967296.0f   /* 2^32: multiplying a coefficient by it is exact */
+#define NAE_ATAN_TINY 7.888609052e-31f /* 2^-100 */
+#define NAE_RCP_MAGIC 0x7EF311C7u      /* integer seed of 1/x: relative error < 0.13, three Newton steps -> < 1e-7 */
 
 /* 1/sqrt(2) rounded to f32, used by the 8-point butterflies */
 #define NAE_SQRT1_2 0.70710678118654752440f

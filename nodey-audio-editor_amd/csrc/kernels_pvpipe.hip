@@ -1,74 +1,113 @@
-// kernels_pvpipe.hip — pass 3 of the phase vocoder (K7) as a three-role wave pipeline for gfx950.
+// kernels_pvpipe.hip — pass 3 of the phase vocoder (K7) as a four-role wave pipeline for gfx950.
 //
-// Why a pipeline.  On gfx950 one wave issues at most one vector instruction per 4.5-5 cycles, while a SIMD with 6-8
-// resident waves issues one per 1.0-1.6 cycles (profiles/r02_valu_issue.md).  A stream-channel of the vocoder is a serial
-// chain of frames (integer phase accumulator, overlap-add), so "one wave per stream-channel" (the round-1 kernel:
-// 239 VGPRs, 2 waves per SIMD on the 2048 stream-channels of BASELINE.json configs[4]) leaves more than half of the
-// vector issue slots empty.  Here each stream-channel is served by THREE waves, one per stage, that hand a frame on
-// through LDS once per step, and every stage fits 80 VGPRs (6 waves per SIMD):
+// Why a pipeline.  On gfx950 one wave issues at most one vector instruction per 4.5-5 cycles, while a SIMD with 8 resident
+// waves issues one per 1.0-1.3 cycles (profiles/r02_valu_issue.md).  A stream-channel of the vocoder is a serial chain of
+// frames (integer phase accumulator, overlap-add), so "one wave per stream-channel" leaves most issue slots empty.  Here a
+// frame passes through FOUR waves, one per role, that hand it on through LDS once per step, and every role fits 64 VGPRs:
+// a 1024-thread workgroup is 4 slots x 4 roles, two workgroups fill a CU (32 waves, 8 per SIMD — each SIMD hosts one wave
+// of every role of two slots):
 //
-//   step t:   R1  frame t    load, Hann window, forward FFT                         -> Z   (its own FFT scratch)
-//             R2  frame t-1  r2c split, atan2 -> Q0.32, exact phase advance, rotate  -> Y   (hand-off buffer)
-//             R3  frame t-2  c2r pre-twiddle, inverse FFT (by forward FFT), overlap-add, store the finished hop block
+//   step t:   R1   frame t    load, Hann window, forward FFT                                         -> Z   (its own FFT scratch)
+//             R2a  frame t-1  bins lane+64r, r = 0..3: r2c split, atan2 -> Q0.32, phase advance, rotate -> Y   (hand-off buffer)
+//             R2b  frame t-1  the same for r = 4..7 and bin 512
+//             R3   frame t-2  c2r pre-twiddle, inverse FFT (by forward FFT), overlap-add, store the finished hop block
 //
-// A step has two workgroup barriers: after A the consumers (R2, R3) read what the producers left in step t-1 into
-// registers; after B the producers overwrite.  So the hand-off buffers need no double buffering and one stream-channel
-// costs 2 x 4608 B (FFT scratch of R1 / R3) + 4160 B (Y) of LDS; four 384-thread workgroups (one stereo stream, or two
-// mono streams, each) fit a CU: 4 x (12352 B tables + 2 x 13376 B) = 156416 B of the 160 KiB.
+// (round 2 ran three roles at 80 VGPRs / 6 waves per SIMD: the phase role carried half of a frame's ~1100 vector
+// instructions and, issuing at the single-wave rate, set the step; profiles/r02_pipe_stamps*.txt.)
+// A step has two workgroup barriers: after A the consumers read what the producers left in step t-1 into registers;
+// after B the producers overwrite.  So the hand-off buffers need no double buffering and one slot costs
+// 2 x 4608 B (FFT scratch of R1 / R3) + 4160 B (Y) of LDS.
+//
+// Slots.  kG = 1: the four slots of a workgroup are four stream-channels (two stereo streams) — the regime of large
+// batches (>= 1024 stream-channels: one tile per stream-channel, no pass 1, nothing analysed twice).
+// kG = 2 / 4 ("frame-interleaved"): the slots of a unit are kG CONSECUTIVE FRAMES of ONE stream-channel and a step
+// advances it by kG frames.  FFTs, split, atan2, rotation are independent per frame; what is sequential is
+//   * the Q0.32 phase: frame f needs Qa of f-1 and Qs of f-1.  R2 analyses frame f in step t and leaves Qa in LDS; in
+//     step t+1 it fetches its predecessor's Qa, forms its increment (exact integers), leaves it in LDS, and behind the
+//     next barrier every R2 wave sums the increments of the slots up to its own onto the running phase (one add per bin);
+//   * the overlap-add: a hop block sums quarters of four consecutive frames = four different slots.  R3 leaves quarters
+//     1..3 of its windowed frame in LDS and, one step later, the wave that holds the block's LAST frame adds them in
+//     frame order — the order of the kG = 1 registers and of the oracle, so all modes give the same samples.
+// This is what small batches run (the 128 streams one rank of an 8-GPU job owns are 256 stream-channels = one
+// workgroup per CU): no time tiles, no pass 1, no second analysis.  Fewer stream-channels still get tiles (nae_pick_pv_shape).
 //
 // The arithmetic — and therefore every integer phase — is the canonical one of DESIGN.md §3 (same dft8_fwd / cmul_tw /
-// atan2_q32 / phase_inc as the other kernels); only where data waits between operations differs.
+// atan2_q32 / phase increment as the other kernels); only where data waits between operations differs.
 // Replaces: SoundTouch behind /root/reference/src/processor/audio-velocity.cpp:369-428 (algorithm differs: DESIGN.md §3).
 #include "stft_common.h"
 
 namespace nae {
 
-constexpr int kPipeSc = 4;                                  // stream-channels per workgroup: 12 waves = 3 per SIMD, so two
-                                                            // workgroups pack a CU exactly (6-wave workgroups left one in four out)
-constexpr int kPipeThreads = 64 * 3 * kPipeSc;              // 768: waves 0-3 = R1, 4-7 = R2, 8-11 = R3 (of sc 0..3)
+constexpr int pipe_threads(int kS) { return 64 * 4 * kS; }   // kS slots: waves [0,kS) = R1, [kS,2kS) = R2a, [2kS,3kS) = R2b, [3kS,4kS) = R3
 constexpr int kYCf = 520;                                   // Y[0..512] natural order
 constexpr size_t kPipeLdsTables = NAE_FFT_N * sizeof(float) + (kT1024Pad + 64 + kTwaCf) * sizeof(cf);
-constexpr size_t kPipeLdsPerSc = (2 * kPadScratchCf + kYCf) * sizeof(cf);
-constexpr size_t kPipeLds = kPipeLdsTables + kPipeSc * kPipeLdsPerSc;
-static_assert(2 * kPipeLds <= 160 * 1024, "two workgroups per CU");
+constexpr size_t kPipeLdsPerSlot = (2 * kPadScratchCf + kYCf) * sizeof(cf);
+// frame-interleaved modes: per slot, analysis phases of the last two steps, one phase increment, and the quarters 1..3 of
+// the windowed frames of the last kOlaGens steps (a block's oldest frame lies ceil(3 / kG) steps back)
+constexpr int pipe_ola_gens(int kG) { return kG >= 3 ? 2 : 3; }
+constexpr int kOlaQuarter = 256;                            // floats
+constexpr size_t pipe_lds_x_per_slot(int kG) { return kG == 1 ? 0 : 3 * kPhasePad * sizeof(uint32_t) + (size_t)pipe_ola_gens(kG) * 3 * kOlaQuarter * sizeof(float); }
+constexpr size_t pipe_lds(int kG, int kS) { return kPipeLdsTables + kS * (kPipeLdsPerSlot + pipe_lds_x_per_slot(kG)); }
+static_assert(2 * pipe_lds(1, 4) <= 160 * 1024 && 4 * pipe_lds(1, 2) <= 160 * 1024, "two / four workgroups per CU");
+static_assert(pipe_lds(2, 4) <= 160 * 1024 && pipe_lds(4, 4) <= 160 * 1024, "one workgroup per CU");
 
 // every LDS operation of this wave has completed, then the workgroup barrier (vector-memory operations stay in flight:
 // the frame prefetch of R1 and the block stores of R3 must not be drained twice per step)
 __device__ __forceinline__ void pipe_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-#ifdef NAE_PIPE_STAMPS
-// diagnostic build only (tools/pipe_stamps.sh): s_memtime around both barriers of steps 200..207, workgroup 0
-__device__ unsigned long long g_pipe_stamps[12 * 8 * 4];
-__device__ unsigned long long g_pipe_total[4 * 64];      // {cycles, realtime ticks, steps, xcc/hw id} of wave 0 of 64 sampled workgroups
-#define PIPE_BARRIER(t, which)                                                                                              \
-    do {                                                                                                                    \
-        const bool st_ = blockIdx.x == 0 && (t) >= 200 && (t) < 208;                                                        \
-        const unsigned long long a_ = __builtin_amdgcn_s_memtime();                                                         \
-        pipe_barrier();                                                                                                     \
-        const unsigned long long b_ = __builtin_amdgcn_s_memtime();                                                         \
-        if (st_ && lane == 0) { g_pipe_stamps[(wave * 8 + ((t) - 200)) * 4 + 2 * (which)] = a_; g_pipe_stamps[(wave * 8 + ((t) - 200)) * 4 + 2 * (which) + 1] = b_; } \
-    } while (0)
-#else
-#define PIPE_BARRIER(t, which) pipe_barrier()
-#endif
-
-// Issue priority.  Two workgroups share a CU and the hardware arbitrates equal priorities by age: measured (tools/pipe_stamps.py)
-// the workgroup that arrived first runs a step in 4700 cycles, its neighbour in 7060, on every CU — the first finishes a
-// third earlier and the CU then runs half empty.  So the two take turns: a workgroup learns whether it was the first or the
-// second on its CU (g_cu_arrivals, counted per physical CU, never reset: only the parity is used) and raises its priority on
-// alternate steps (6.95-7.03 ms against 7.14-7.17 on one box; raising the role on a step's critical path as well — R1 between
-// barriers A and B, R3 between B and A — made it 7.4).
+// Issue priority (kG = 1).  Two workgroups share a CU and the hardware arbitrates equal priorities by age, so the workgroup that
+// arrived first runs its steps faster than its neighbour on every CU (profiles/r02_pipe_stamps_per_cu.txt).  They take turns: a
+// workgroup learns whether it was the first or the second on its CU (g_cu_arrivals, counted per physical CU, never reset: only
+// the parity is used) and raises its priority on alternate steps; the role that ends a step's critical path (R3) sits one
+// level above its workgroup's.  (Measured and dropped: keeping the pair level by feedback — each workgroup publishing its step
+// counter, whoever is behind at the higher priority — levels them at the pace of the SLOWER one: 7.8 against 7.3 ms.)
 __device__ unsigned g_cu_arrivals[8 * 4 * 16];
-__device__ __forceinline__ void pipe_prio(int t, int slot)
+__device__ __forceinline__ void pipe_prio(int t, int slot, int role, int mode)
 {
-    if ((t + slot) & 1) __builtin_amdgcn_s_setprio(2);      // wave-uniform
-    else __builtin_amdgcn_s_setprio(0);
+    if (mode == 1) return;
+    const int lvl = (((t + slot) & 1) ? 2 : 0) + (role == 3 && mode != 2 ? 1 : 0);      // wave-uniform
+    if (lvl == 0) __builtin_amdgcn_s_setprio(0);
+    else if (lvl == 1) __builtin_amdgcn_s_setprio(1);
+    else if (lvl == 2) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(3);
 }
 
-template <bool kUnit>
-__global__ __launch_bounds__(kPipeThreads, 6) void pv_pipe_kernel(SigViewD src, PvParams p, long long n_sc,
-                                                                 const uint32_t* __restrict__ base_phase, OutViewD out, Tables tb)
+// the lane index as a value the optimiser cannot see through: addresses derived from it are recomputed where they are used
+// (one to four instructions each) instead of being hoisted out of the frame loop, where each would pin a VGPR of the 64
+__device__ __forceinline__ int pipe_lane(int lane)
 {
+    asm volatile("" : "+v"(lane));
+    return lane;
+}
+
+// exact phase increment of one hop for bin k: adv + round(dw * R / 2^24)
+__device__ __forceinline__ uint32_t pipe_inc(uint32_t qa, uint32_t qp, unsigned k, unsigned d, unsigned R)
+{
+    const uint32_t e = ((k * d) & (NAE_FFT_N - 1)) << 22;
+    const int32_t dw = (int32_t)(qa - qp - e);
+    const uint32_t adv = ((k * NAE_HOP) & (NAE_FFT_N - 1)) << 22;
+    const long long scaled = ((long long)dw * (long long)(int32_t)R + (1ll << (NAE_R_FRAC_BITS - 1))) >> NAE_R_FRAC_BITS;
+    return adv + (uint32_t)scaled;
+}
+
+// synthesis bin X e^{i (qs - qa)} (tolerance path: v_sin / v_cos take turns)
+__device__ __forceinline__ cf pipe_rotate(cf x, uint32_t qs, uint32_t qa)
+{
+    const float ph = (float)(int32_t)(qs - qa) * (1.0f / 4294967296.0f);
+    const float cs = __builtin_amdgcn_cosf(ph), sn = __builtin_amdgcn_sinf(ph);
+    return cf{__builtin_fmaf(x.x, cs, -(x.y * sn)), __builtin_fmaf(x.x, sn, x.y * cs)};
+}
+
+template <bool kUnit, int kG, int kS, bool kRich>
+__global__ __launch_bounds__(pipe_threads(kS), kRich ? (kS == 4 ? 4 : 2) : 8) void pv_pipe_kernel(SigViewD src, PvParams p, long long n_sc,
+                                                                               const uint32_t* __restrict__ base_phase, OutViewD out, Tables tb)
+{
+    constexpr int kPipeSlots = kS, kPipeThreads = pipe_threads(kS);
+    static_assert(kS % kG == 0, "a unit's frames share a workgroup");
+    static_assert(kG == 1 || kRich, "the frame-interleaved modes run one workgroup per CU");
+    constexpr int kUnits = kPipeSlots / kG;                  // stream-channels (x tile) per workgroup
+    constexpr int kDepth = kG == 1 ? 2 : 4;                  // steps a frame needs beyond its R1 step
+    constexpr int kGens = pipe_ola_gens(kG);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* hann = reinterpret_cast<float*>(smem);
     cf* t1024 = reinterpret_cast<cf*>(smem + NAE_FFT_N * sizeof(float));
@@ -79,38 +118,45 @@ __global__ __launch_bounds__(kPipeThreads, 6) void pv_pipe_kernel(SigViewD src, 
     if (threadIdx.x < 64) w64[threadIdx.x] = tb.w512[8 * (threadIdx.x >> 3) * (threadIdx.x & 7)];
     fill_twa(twa, tb.w512, threadIdx.x, kPipeThreads);
     __shared__ int s_slot;
-    if (threadIdx.x == 0) {
+    if (kG == 1 && threadIdx.x == 0) {
         const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);            // HW_ID: CU 8-11, SE 13-14
         const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 7u;     // XCC_ID
         const unsigned key = (xcc * 4 + ((hw >> 13) & 3u)) * 16 + ((hw >> 8) & 15u);
         s_slot = (int)(atomicAdd(&g_cu_arrivals[key], 1u) & 1u);
     }
     __syncthreads();
-    const int slot = __builtin_amdgcn_readfirstlane(s_slot);
+    const int prio_slot = kG == 1 ? __builtin_amdgcn_readfirstlane(s_slot) : 0;
 
     const int wave = wave_id();
-    const int role = wave / kPipeSc, half = wave % kPipeSc;  // scalars
+    const int role = wave / kPipeSlots, slot = wave % kPipeSlots;   // scalars
+    const int unit = slot / kG, j = slot % kG;                      // j: frame of the step this slot works on (kG > 1)
     const int lane = threadIdx.x & 63;
-    // stereo: a workgroup owns both channels of (stream, tile), so their block stores of an interleaved destination
-    // happen in the same step and merge in L2; mono: two consecutive (stream, tile) items
+    // stereo: units 2i, 2i+1 are the two channels of one (stream, tile), so with kG <= 2 their block stores of an interleaved
+    // destination happen in the same step and merge in L2; mono: consecutive (stream, tile) items
+    const long long ug = (long long)kUnits * blockIdx.x + unit;
     long long sc;
     int tile;
     if (p.ch == 2) {
-        const long long pair = 2 * (long long)blockIdx.x + (half >> 1);      // (stream, tile), tile fastest
-        sc = 2 * (pair / p.n_tiles) + (half & 1);
+        const long long pair = ug >> 1;                          // (stream, tile), tile fastest
+        sc = 2 * (pair / p.n_tiles) + (ug & 1);
         tile = (int)(pair % p.n_tiles);
     } else {
-        const long long item = kPipeSc * (long long)blockIdx.x + half;
-        sc = item / p.n_tiles;
-        tile = (int)(item % p.n_tiles);
+        sc = ug / p.n_tiles;
+        tile = (int)(ug % p.n_tiles);
     }
     if (sc >= n_sc) return;                                  // a terminated wave no longer counts at s_barrier
     const long long s_idx = sc / p.ch;
     const int c = (int)(sc % p.ch);
 
-    cf* S1 = reinterpret_cast<cf*>(smem + kPipeLdsTables + half * kPipeLdsPerSc);
+    cf* S1 = reinterpret_cast<cf*>(smem + kPipeLdsTables + slot * kPipeLdsPerSlot);
     cf* Y = S1 + kPadScratchCf;
     cf* S3 = Y + kYCf;
+    // frame-interleaved exchange areas, indexed by slot: QA[2][520] | INC[520] | OL[kGens][3][256]
+    unsigned char* xbase = smem + kPipeLdsTables + kPipeSlots * kPipeLdsPerSlot;
+    constexpr size_t kXPer = pipe_lds_x_per_slot(kG);
+    auto x_qa = [&](int sl, int gen) { return reinterpret_cast<uint32_t*>(xbase + sl * kXPer) + gen * kPhasePad; };
+    auto x_inc = [&](int sl) { return reinterpret_cast<uint32_t*>(xbase + sl * kXPer) + 2 * kPhasePad; };
+    auto x_ola = [&](int sl, int gen) { return reinterpret_cast<float*>(xbase + sl * kXPer + 3 * kPhasePad * sizeof(uint32_t)) + gen * 3 * kOlaQuarter; };
 
     const long long b0 = p.f_origin + (long long)tile * p.tile;      // first output block == first frame of the tile
     long long b_end = b0 + p.tile;
@@ -120,129 +166,255 @@ __global__ __launch_bounds__(kPipeThreads, 6) void pv_pipe_kernel(SigViewD src, 
     const long long f_first = (b0 > 0 ? b0 - 1 : 0);                   // frame b0-1 only primes the previous phase
     const int n = (int)(f_end - f_first);
     if (n <= 0) return;
+    const int steps = (n + kG - 1) / kG;
+    const int T = steps + kDepth;
+    /*pipe:begin*/
 
-#ifdef NAE_PIPE_STAMPS
-    const unsigned long long tot_c0 = __builtin_amdgcn_s_memtime(), tot_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
     if (role == 0) {
         // ------------------------------------------------------------------------------------------ R1: analysis FFT
         ChanView in{src.base + s_idx * src.ss + c * src.cs, src.fs, p.in_len};
-        const FftLds L = make_fft_lds(S1, twa, w64, lane);
-        const cf* hw = reinterpret_cast<const cf*>(hann) + lane;             // window of samples 2 (lane + 64 j), +1
         cf nxt[8], va[8];
-        load_frame_raw<kUnit>(nxt, in, frame_start(p, f_first), lane);
+        if (j < n) load_frame_raw<kUnit>(nxt, in, frame_start(p, f_first + j), lane);
+        // kRich (one workgroup per CU: 128 VGPRs per wave): window and both twiddle sets stay in registers — 30 LDS reads less
+        // per frame and one round trip less on the step's critical path
+        cf r_w[8], r_ta[7], r_tb[7];
+        if (kRich) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) r_w[r] = lds_ld(reinterpret_cast<const cf*>(hann) + lane + 64 * r);
+#pragma unroll
+            for (int q = 0; q < 7; q++) { r_ta[q] = lds_ld(twa + lane + 64 * q); r_tb[q] = lds_ld(w64 + 8 * (lane & 7) + q + 1); }
+        }
 #pragma unroll 1
-        for (int t = 0; t < n + 2; t++) {
-            PIPE_BARRIER(t, 0);                               // A
-            pipe_prio(t, slot);
-            if (t < n) {
-                // register-only part while R2 reads Z of frame t-1 out of this wave's scratch
-                // (all reads of a phase are requested before the first one is used: the accesses are volatile, so the compiler
-                // keeps them where they are written, and one read per product would cost one LDS round trip each)
-                cf w[8];
+        for (int t = 0; t < T; t++) {
+            const bool cur = kG * t + j < n;
+            pipe_barrier();                                   /*A*/
+            if (kG == 1) pipe_prio(t, prio_slot, role, p.dbg1);
+            if (cur) {
+                // register-only part while R2 reads Z of the previous step out of this wave's scratch.  Window and pass-A
+                // twiddles are requested together (one LDS round trip): the accesses are volatile, so the compiler keeps them
+                // where they are written, and one read per product would cost one round trip each
+                const int la = pipe_lane(lane);
+                const cf* hw = reinterpret_cast<const cf*>(hann) + la;      // window of samples 2 (lane + 64 r), +1
+                const cf* ta = twa + la;
+                if (kRich) {
 #pragma unroll
-                for (int j = 0; j < 8; j++) w[j] = lds_ld(hw + 64 * j);
+                    for (int r = 0; r < 8; r++) va[r] = cf{nxt[r].x * r_w[r].x, nxt[r].y * r_w[r].y};
+                    fft512_pad_a_tw(va, r_ta);
+                } else {
+                    cf w[8], tw[7];
 #pragma unroll
-                for (int j = 0; j < 8; j++) va[j] = cf{nxt[j].x * w[j].x, nxt[j].y * w[j].y};
-                fft512_pad_a(va, L);
+                    for (int r = 0; r < 8; r++) w[r] = lds_ld(hw + 64 * r);
+#pragma unroll
+                    for (int q = 0; q < 7; q++) tw[q] = lds_ld(ta + 64 * q);
+#pragma unroll
+                    for (int r = 0; r < 8; r++) va[r] = cf{nxt[r].x * w[r].x, nxt[r].y * w[r].y};
+                    fft512_pad_a_tw(va, tw);
+                }
             }
-            PIPE_BARRIER(t, 1);                               // B: R2 holds X of frame t-1 in registers
-            if (t < n) {
-                fft512_pad_bc(va, L);
+            pipe_barrier();                                   /*B*/
+            if (cur) {
+                const FftLds L = make_fft_lds(S1, twa, w64, pipe_lane(lane));
+                cf none[8];
+                fft512_pad_bc_g<kRich, false>(va, L, r_tb, nullptr, none);
 #pragma unroll
                 for (int r = 0; r < 8; r++) lds_st(L.nat + 64 * r, va[r]);
                 if (lane == 0) S1[512] = va[0];               // so that the mirror of bin 0 is read like any other
-                // request the next frame now: R1 is the shortest role, the loads land while it waits at the barriers
-                if (t + 1 < n) load_frame_raw<kUnit>(nxt, in, frame_start(p, f_first + t + 1), lane);
+                // request the next frame now: the loads land while the wave waits at the barriers
+                if (kG * (t + 1) + j < n) load_frame_raw<kUnit>(nxt, in, frame_start(p, f_first + kG * (t + 1) + j), lane);
             }
         }
-#ifdef NAE_PIPE_STAMPS
-        if (wave == 0 && lane == 0 && (blockIdx.x & 7) == 0 && (blockIdx.x >> 3) < 64) {
-            unsigned long long* o = g_pipe_total + 4 * (blockIdx.x >> 3);
-            o[0] = __builtin_amdgcn_s_memtime() - tot_c0; o[1] = __builtin_amdgcn_s_memrealtime() - tot_r0; o[2] = n + 2;
-            o[3] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4);
-        }
-#endif
-    } else if (role == 1) {
-        // ------------------------------------------------------------------------------------------ R2: phases
-        const cf* Zn = S1 + lane;
-        const cf* Zm = S1 + 64 - lane;
-        cf* Yn = Y + lane;
-        const cf* tsp = t1024 + lane;
-        uint32_t qs[9], qp[9];
+        /*pipe:r1-end*/
+    } else if (role <= 2) {
+        // ------------------------------------------------------------------------------------------ R2a / R2b: phases
+        // Bins in mirror pairs: a lane owns k = lane + 64 (2 h + i) and 512 - k, i = 0, 1 (items 2 i and 2 i + 1) — 0..127 and
+        // 385..512 for h = 0, 128..255 and 257..384 for h = 1 — and h = 1 also owns the self-mirrored bin 256 (item 4, lane 0).
+        // One pair of reads (A = Z[k], B = Z[512 - k]) gives both spectra: the mirror's E and O are (Ex, -Ey) and (-Ox, Oy) —
+        // exact negations and commuted sums of the canonical formula, so every phase keeps its bits — and both rotated bins of a
+        // pair meet in one lane, where the c2r pre-twiddle of R3's FFT input needs them: what goes to R3 is that input, not Y.
+        const int h = role - 1;
+        const int k0 = lane + 128 * h;                        // items 0 / 2: k0, k0 + 64; items 1 / 3: 512 - k0, 448 - k0
+        const bool pair0_is_dc = (h == 0) && (lane == 0);     // the pair (0, 512): both real; bin 512's phase is its sign
+        cf tk[2], tm[2];                                      // split twiddles of the pair's bins (loop-invariant: 8 VGPRs)
+#pragma unroll
+        for (int i = 0; i < 2; i++) { tk[i] = tb.t1024[k0 + 64 * i]; tm[i] = tb.t1024[512 - k0 - 64 * i]; }
+        const cf t256 = tb.t1024[256];
+        uint32_t qs[5], qp[5];
         {
             const uint32_t* bp = base_phase + (sc * p.phase_tiles + (long long)tile * p.phase_step) * kT1024Pad;
 #pragma unroll
-            for (int r = 0; r < 8; r++) { qs[r] = bp[lane + 64 * r]; qp[r] = 0; }
-            qs[8] = bp[512];
-            qp[8] = 0;
-        }
-        long long s_prev = 0;
-#pragma unroll 1
-        for (int t = 0; t < n + 2; t++) {
-            const bool active = (t >= 1) && (t <= n);
-            const long long f = f_first + t - 1;
-            PIPE_BARRIER(t, 0);                               // A: Z of frame f is complete
-            pipe_prio(t, slot);
-            cf va[8], nyq{0.0f, 0.0f};
-            if (active) {
-                cf vb[8];
+            for (int i = 0; i < 2; i++) { qs[2 * i] = bp[k0 + 64 * i]; qs[2 * i + 1] = bp[512 - k0 - 64 * i]; }
+            qs[4] = bp[256];
 #pragma unroll
-                for (int r = 0; r < 8; r++) { va[r] = lds_ld(Zn + 64 * r); vb[r] = lds_ld(Zm + 448 - 64 * r); }
-                const cf z0 = S1[0];
+            for (int q = 0; q < 5; q++) qp[q] = 0;
+        }
+        cf hx[5];                                             // kG > 1: the frame analysed in the previous step
+        uint32_t hqa[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 5; q++) hx[q] = cf{0.0f, 0.0f};
+        // phase increment of all items of this lane (exact integers); the mirror's k d mod 1024 follows from the bin's
+        auto inc_items = [&](const uint32_t (&qa)[5], const uint32_t (&qv)[5], unsigned d, unsigned R, uint32_t (&inc)[5]) {
+            const int kk = pipe_lane(k0);
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                inc[2 * i] = pipe_inc(qa[2 * i], qv[2 * i], (unsigned)(kk + 64 * i), d, R);
+                inc[2 * i + 1] = pipe_inc(qa[2 * i + 1], qv[2 * i + 1], (unsigned)(512 - kk - 64 * i), d, R);
+            }
+            inc[4] = (h == 1) ? pipe_inc(qa[4], qv[4], 256u, d, R) : 0u;
+        };
+        // rotation by the phase difference and the in-lane c2r pre-twiddle: R3's FFT input Zin[k], Zin[512 - k]
+        // (conjugated, inverse = conj(FFT(conj Z)) / 512; 2E, 2D: see kGain)
+        auto synth_items = [&](const cf (&x)[5], const uint32_t (&qsv)[5], const uint32_t (&qav)[5]) {
+            const int kk = pipe_lane(k0);
+            cf* Yk = Y + kk;
+            cf* Ym = Y + 512 - kk;
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                cf yk = pipe_rotate(x[2 * i], qsv[2 * i], qav[2 * i]);
+                cf ym = pipe_rotate(x[2 * i + 1], qsv[2 * i + 1], qav[2 * i + 1]);
+                if (i == 0 && pair0_is_dc) { yk.y = 0.0f; ym.y = 0.0f; }     // c2r ignores Im Y[0] and Im Y[512]
+                const cf E{yk.x + ym.x, yk.y - ym.y};
+                const cf D{yk.x - ym.x, yk.y + ym.y};
+                const cf Q{__builtin_fmaf(tk[i].x, D.x, tk[i].y * D.y), __builtin_fmaf(tk[i].x, D.y, -(tk[i].y * D.x))};
+                lds_st(Yk + 64 * i, cf{E.x - Q.y, -(E.y + Q.x)});
+                // index 512 - k: the roles of the two bins swap
+                const cf Qm{__builtin_fmaf(tm[i].x, -D.x, tm[i].y * D.y), __builtin_fmaf(tm[i].x, D.y, tm[i].y * D.x)};
+                if (!(i == 0 && pair0_is_dc)) lds_st(Ym - 64 * i, cf{E.x - Qm.y, E.y - Qm.x});
+            }
+            if (h == 1 && lane == 0) {
+                const cf y = pipe_rotate(x[4], qsv[4], qav[4]);
+                const cf E{y.x + y.x, y.y - y.y};
+                const cf D{y.x - y.x, y.y + y.y};
+                const cf Q{__builtin_fmaf(t256.x, D.x, t256.y * D.y), __builtin_fmaf(t256.x, D.y, -(t256.y * D.x))};
+                Y[256] = cf{E.x - Q.y, -(E.y + Q.x)};
+            }
+        };
+#pragma unroll 1
+        for (int t = 0; t < T; t++) {
+            const int ia = kG * (t - 1) + j;                  // index (from f_first) of the frame analysed in this step
+            const bool act_a = t >= 1 && ia < n;
+            const long long fa = f_first + ia;
+            const int ib = ia - kG;                           // kG > 1: the frame whose phase is advanced in this step
+            const bool act_b = kG > 1 && t >= 2 && ib < n;
+            const long long fb = f_first + ib;
+            pipe_barrier();                                   /*A*/  // Z of frame fa is complete
+            if (kG == 1) pipe_prio(t, prio_slot, role, p.dbg1);
+            cf va[5];
+            if (act_a) {
+                const int kk = pipe_lane(k0);
+                const cf* Zk = S1 + kk;
+                const cf* Zm = S1 + 512 - kk;
+                cf A[2], B[2];
+#pragma unroll
+                for (int i = 0; i < 2; i++) { A[i] = lds_ld(Zk + 64 * i); B[i] = lds_ld(Zm - 64 * i); }
+                cf z256{0.0f, 0.0f};
+                if (h == 1) z256 = lds_ld(S1 + 256);
                 // r2c split -> 2 X (phases are scale-invariant; the factor is undone in R3's output gain: a factor 2 is
                 // exact in every product on the way)
-                {
-                    const cf E = cf{z0.x + z0.x, z0.y - z0.y};
-                    const cf O = cf{z0.x - z0.x, z0.y + z0.y};
-                    const cf P = cmul_tw(O, t1024[512]);
-                    nyq = cf{E.x + P.y, E.y - P.x};
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    const cf E = cf{A[i].x + B[i].x, A[i].y - B[i].y};
+                    const cf O = cf{A[i].x - B[i].x, A[i].y + B[i].y};
+                    const cf P = cmul_tw(O, tk[i]);
+                    va[2 * i] = cf{E.x + P.y, E.y - P.x};
+                    const cf Em = cf{E.x, -E.y};
+                    const cf Om = cf{-O.x, O.y};
+                    const cf Pm = cmul_tw(Om, tm[i]);
+                    va[2 * i + 1] = cf{Em.x + Pm.y, Em.y - Pm.x};
                 }
-                cf tw[8];
-#pragma unroll
-                for (int r = 0; r < 8; r++) tw[r] = lds_ld(tsp + 64 * r);
-#pragma unroll
-                for (int r = 0; r < 8; r++) {
-                    const cf A = va[r], B = vb[r];
-                    const cf E = cf{A.x + B.x, A.y - B.y};
-                    const cf O = cf{A.x - B.x, A.y + B.y};
-                    const cf P = cmul_tw(O, tw[r]);
-                    va[r] = cf{E.x + P.y, E.y - P.x};
+                {
+                    const cf E = cf{z256.x + z256.x, z256.y - z256.y};
+                    const cf O = cf{z256.x - z256.x, z256.y + z256.y};
+                    const cf P = cmul_tw(O, t256);
+                    va[4] = cf{E.x + P.y, E.y - P.x};
                 }
             }
-            PIPE_BARRIER(t, 1);                               // B: R1 may overwrite its scratch
-            if (active) {
-                const long long s = frame_start(p, f);
-                uint32_t qa[9];
-                phases_of(va, nyq, qa);
-                if (f >= b0) {
-                    if (f == 0) {
+            if (kG > 1) {
+                // increment of the held frame fb: its predecessor's analysis phases were left in LDS one step ago (slot j-1), or
+                // two steps ago by the last slot (j = 0)
+                uint32_t inc[5] = {0, 0, 0, 0, 0};
+                const int kk = pipe_lane(k0);
+                if (act_b && fb >= b0) {
+                    if (fb == 0) {
 #pragma unroll
-                        for (int r = 0; r < 9; r++) qs[r] += qa[r];
+                        for (int q = 0; q < 5; q++) inc[q] = hqa[q];   // the "increment" of frame 0 is its analysis phase
                     } else {
-                        const unsigned d = (unsigned)(s - s_prev);
+                        const uint32_t* pq = j > 0 ? x_qa(slot - 1, (t - 1) & 1) : x_qa(slot + kG - 1, t & 1);
+                        uint32_t pv[5];
+#pragma unroll
+                        for (int i = 0; i < 2; i++) { pv[2 * i] = pq[kk + 64 * i]; pv[2 * i + 1] = pq[512 - kk - 64 * i]; }
+                        pv[4] = pq[256];
+                        const unsigned d = (unsigned)(frame_start(p, fb) - frame_start(p, fb - 1));
                         const unsigned R = (d == (unsigned)p.d0) ? p.r_q24_0 : p.r_q24_1;
-                        phase_inc(qa, qp, qs, lane, d, R);
+                        inc_items(hqa, pv, d, R, inc);
                     }
                 }
+                uint32_t* pi = x_inc(slot);
 #pragma unroll
-                for (int r = 0; r < 9; r++) qp[r] = qa[r];
-                s_prev = s;
-                if (f >= b0) {
-                    // synthesis spectrum |X| e^{2 pi i qs} == X e^{i (qs - qa)}: rotate by the phase difference (tolerance path)
+                for (int i = 0; i < 2; i++) { pi[kk + 64 * i] = inc[2 * i]; pi[512 - kk - 64 * i] = inc[2 * i + 1]; }
+                if (h == 1 && lane == 0) pi[256] = inc[4];
+            }
+            pipe_barrier();                                   /*B*/  // R1 may overwrite its scratch
+            uint32_t qa[5] = {0, 0, 0, 0, 0};
+            if (act_a) {
 #pragma unroll
-                    for (int r = 0; r < 8; r++) {
-                        const float ph = (float)(int32_t)(qs[r] - qa[r]) * (1.0f / 4294967296.0f);
-                        const float cs = __builtin_amdgcn_cosf(ph), sn = __builtin_amdgcn_sinf(ph);
-                        cf y{__builtin_fmaf(va[r].x, cs, -(va[r].y * sn)), __builtin_fmaf(va[r].x, sn, va[r].y * cs)};
-                        if (r == 0 && lane == 0) y.y = 0.0f;   // c2r ignores Im Y[0]
-                        lds_st(Yn + 64 * r, y);
+                for (int q = 0; q < 4; q++) qa[q] = atan2_q32(va[q].y, va[q].x);
+                if (h == 1) qa[4] = atan2_q32(va[4].y, va[4].x);
+                // bin N/2 of a real signal is real: its phase is 0 or 1/2 turn by the sign of the real part
+                if (pair0_is_dc) qa[1] = (va[1].x < 0.0f) ? 0x80000000u : 0u;
+            }
+            if (kG == 1) {
+                if (act_a) {
+                    if (fa >= b0) {
+                        if (fa == 0) {
+#pragma unroll
+                            for (int q = 0; q < 5; q++) qs[q] += qa[q];
+                        } else {
+                            const unsigned d = (unsigned)(frame_start(p, fa) - frame_start(p, fa - 1));
+                            const unsigned R = (d == (unsigned)p.d0) ? p.r_q24_0 : p.r_q24_1;
+                            uint32_t inc[5];
+                            inc_items(qa, qp, d, R, inc);
+#pragma unroll
+                            for (int q = 0; q < 5; q++) qs[q] += inc[q];
+                        }
                     }
-                    if (lane == 0) {
-                        const float ph = (float)(int32_t)(qs[8] - qa[8]) * (1.0f / 4294967296.0f);
-                        const float cs = __builtin_amdgcn_cosf(ph), sn = __builtin_amdgcn_sinf(ph);
-                        Y[512] = cf{__builtin_fmaf(nyq.x, cs, -(nyq.y * sn)), 0.0f};
+#pragma unroll
+                    for (int q = 0; q < 5; q++) qp[q] = qa[q];
+                    if (fa >= b0) synth_items(va, qs, qa);
+                }
+            } else {
+                if (act_a) {
+                    const int kk = pipe_lane(k0);
+                    uint32_t* pq = x_qa(slot, t & 1);
+#pragma unroll
+                    for (int i = 0; i < 2; i++) { pq[kk + 64 * i] = qa[2 * i]; pq[512 - kk - 64 * i] = qa[2 * i + 1]; }
+                    if (h == 1 && lane == 0) pq[256] = qa[4];
+                }
+                if (act_b) {
+                    // running phase: the increments of the unit's slots up to this one; all of them move the base on
+                    const int kk = pipe_lane(k0);
+                    uint32_t mine[5], base[5];
+#pragma unroll
+                    for (int q = 0; q < 5; q++) { mine[q] = qs[q]; base[q] = qs[q]; }
+#pragma unroll
+                    for (int i2 = 0; i2 < kG; i2++) {
+                        const uint32_t* pi = x_inc(slot - j + i2);
+                        uint32_t v[5];
+#pragma unroll
+                        for (int i = 0; i < 2; i++) { v[2 * i] = pi[kk + 64 * i]; v[2 * i + 1] = pi[512 - kk - 64 * i]; }
+                        v[4] = pi[256];
+#pragma unroll
+                        for (int q = 0; q < 5; q++) {
+                            base[q] += v[q];
+                            if (i2 <= j) mine[q] += v[q];
+                        }
                     }
+#pragma unroll
+                    for (int q = 0; q < 5; q++) qs[q] = base[q];
+                    if (fb >= b0) synth_items(hx, mine, hqa);
+                }
+                if (act_a) {
+#pragma unroll
+                    for (int q = 0; q < 5; q++) { hx[q] = va[q]; hqa[q] = qa[q]; }
                 }
             }
         }
@@ -250,54 +422,109 @@ __global__ __launch_bounds__(kPipeThreads, 6) void pv_pipe_kernel(SigViewD src, 
         // ------------------------------------------------------------------------------------------ R3: synthesis
         float* optr = out.base + s_idx * out.ss + c * out.cs;
         const bool out_vec = (out.fs == 1) && ((reinterpret_cast<uintptr_t>(optr) & 15) == 0);
-        const FftLds L = make_fft_lds(S3, twa, w64, lane);
-        const cf* Yn = Y + lane;
-        const cf* Ym = Y + 64 - lane;
-        const cf* tsp = t1024 + lane;
-        const cf* hw = reinterpret_cast<const cf*>(hann) + lane;
-        // Overlap-add in registers.  Sample n = 2 (lane + 64 r) + {0,1} of a frame falls into hop block r >> 1 at offset
-        // 2 lane + 128 (r & 1) + {0,1}: a lane touches the same 4 offsets of every block, so the 3 open blocks are 12 VGPRs
-        // (the 4th block a frame touches is new).  Block fz-3 is complete once frame fz is in; contributions arrive in
-        // increasing frame order, as in the oracle.  Sums are kept unscaled; the constants of the tolerance path — 1/512
-        // (inverse FFT), 1/2 (c2r pre-twiddle), 1/2 (analysis split) and 2/3 (overlap-add gain) — scale the finished block.
+        // Overlap-add.  Sample n = 2 (lane + 64 r) + {0,1} of a frame falls into hop block r >> 1 at offset
+        // 2 lane + 128 (r & 1) + {0,1}: a lane touches the same 4 offsets of every block.  kG = 1: the 3 open blocks are 12
+        // VGPRs (the 4th block a frame touches is new); block fz-3 is complete once frame fz is in; contributions arrive in
+        // increasing frame order, as in the oracle.  kG > 1: quarters 1..3 go to LDS, quarter 0 waits in 4 VGPRs for the
+        // next step, where the other three quarters of its block are fetched from the slots of the three frames before.
+        // Sums are kept unscaled; the constants of the tolerance path — 1/512 (inverse FFT), 1/2 (c2r pre-twiddle), 1/2
+        // (analysis split) and 2/3 (overlap-add gain) — scale the finished block.
         constexpr float kGain = NAE_OLA_GAIN / 2048.0f;
         float r0[4] = {0.0f, 0.0f, 0.0f, 0.0f}, r1[4] = {0.0f, 0.0f, 0.0f, 0.0f}, r2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll 1
-        for (int t = 0; t < n + 2; t++) {
-            const long long fz = f_first + t - 2;
-            const bool active = (t >= 2) && (fz >= b0);
-            PIPE_BARRIER(t, 0);                               // A: Y of frame fz is complete
-            pipe_prio(t, slot);
-            cf zs[8];
-            if (active) {
-                // c2r pre-twiddle into FFT input layout, conjugated (inverse = conj(FFT(conj Z)) / 512); 2E, 2D: see kGain
+        float y0[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        cf r_w[8], r_ta[7], r_tb[7];                          // kRich: synthesis window and twiddles in registers
+        if (kRich) {
 #pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    cf Xk[4], Xm[4], T[4];
+            for (int r = 0; r < 8; r++) r_w[r] = lds_ld(reinterpret_cast<const cf*>(hann) + lane + 64 * r);
 #pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const int r = 4 * h + q;
-                        Xk[q] = lds_ld(Yn + 64 * r);
-                        Xm[q] = lds_ld(Ym + 448 - 64 * r);
-                        T[q] = lds_ld(tsp + 64 * r);
+            for (int q = 0; q < 7; q++) { r_ta[q] = lds_ld(twa + lane + 64 * q); r_tb[q] = lds_ld(w64 + 8 * (lane & 7) + q + 1); }
+        }
+        bool had = false;                                     // kG > 1: a frame of this slot went through the previous step
+        auto store_block = [&](long long be, const float (&o)[4]) {
+            if (be >= b0 && be < b_end && be * NAE_HOP < p.mid_len) {
+                // buffer stores: scalar descriptor of the block + one 32-bit lane offset (plain pointer stores made hipcc
+                // hoist four 64-bit per-lane addresses out of the frame loop)
+                float* pb = optr + be * NAE_HOP * out.fs;
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(pb, 0, -1, 0x00020000);
+                auto st = [&](unsigned byte_off, float v) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, (int)byte_off, 0, 0); };
+                const int ls = pipe_lane(lane);
+                const unsigned fs4 = 4u * (unsigned)out.fs;                 // bytes between consecutive samples
+                const unsigned oa = 2u * (unsigned)ls * fs4;                // sample 2 lane of the block
+                if ((be + 1) * NAE_HOP <= p.mid_len) {
+                    if (out_vec) {
+                        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                        __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(o[0]), __float_as_uint(o[1])}, rs, (int)(8u * ls), 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(o[2]), __float_as_uint(o[3])}, rs, (int)(512u + 8u * ls), 0, 0);
+                    } else {
+                        st(oa, o[0]); st(oa + fs4, o[1]); st(oa + 128u * fs4, o[2]); st(oa + 129u * fs4, o[3]);
                     }
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const cf E{Xk[q].x + Xm[q].x, Xk[q].y - Xm[q].y};
-                        const cf D{Xk[q].x - Xm[q].x, Xk[q].y + Xm[q].y};
-                        const cf Q{__builtin_fmaf(T[q].x, D.x, T[q].y * D.y), __builtin_fmaf(T[q].x, D.y, -(T[q].y * D.x))};
-                        zs[4 * h + q] = cf{E.x - Q.y, -(E.y + Q.x)};
-                    }
+                } else {
+                    const int rem = (int)(p.mid_len - be * NAE_HOP);
+                    if (2 * ls + 0 < rem) st(oa, o[0]);
+                    if (2 * ls + 1 < rem) st(oa + fs4, o[1]);
+                    if (128 + 2 * ls < rem) st(oa + 128u * fs4, o[2]);
+                    if (129 + 2 * ls < rem) st(oa + 129u * fs4, o[3]);
                 }
             }
-            PIPE_BARRIER(t, 1);                               // B: R2 may overwrite Y
+        };
+#pragma unroll 1
+        for (int t = 0; t < T; t++) {
+            const int iz = kG * (t - (kDepth - (kG == 1 ? 0 : 1))) + j;      // kG = 1: t - 2;  kG > 1: t - 3
+            const long long fz = f_first + iz;
+            const bool active = iz >= 0 && iz < n && fz >= b0;
+            pipe_barrier();                                   /*A*/  // the FFT input of frame fz is complete
+            if (kG == 1) pipe_prio(t, prio_slot, role, p.dbg1);
+            cf zs[8];
             if (active) {
-                fft512_pad_a(zs, L);
-                // (the synthesis window is requested now: its round trip hides behind passes B and C)
-                cf wn[8];
+                // FFT input and pass-A twiddles in one round trip; pass A is register-only, so it runs on this side of barrier B
+                const int la = pipe_lane(lane);
+                const cf* Zi = Y + la;
+                const cf* ta = twa + la;
 #pragma unroll
-                for (int r = 0; r < 8; r++) wn[r] = lds_ld(hw + 64 * r);
-                fft512_pad_bc(zs, L);
+                for (int r = 0; r < 8; r++) zs[r] = lds_ld(Zi + 64 * r);
+                if (kRich) {
+                    fft512_pad_a_tw(zs, r_ta);
+                } else {
+                    cf tw[7];
+#pragma unroll
+                    for (int q = 0; q < 7; q++) tw[q] = lds_ld(ta + 64 * q);
+                    fft512_pad_a_tw(zs, tw);
+                }
+            }
+            if (kG > 1 && had) {
+                // the block that the frame of the previous step completed: quarters 3, 2, 1 of the three frames before it
+                // (slot (j - i) mod kG, floor((j - i) / kG) steps earlier), then the own quarter 0 — the frame order
+                const long long be = fz - kG - 3;
+                if (be >= b0) {
+                    float o[4];
+                    const int lq = pipe_lane(lane);
+#pragma unroll
+                    for (int i = 3; i >= 1; i--) {
+                        const int rel = j - i;                                   // < 0: an earlier step
+                        const int back = rel >= 0 ? 0 : (-rel + kG - 1) / kG;
+                        const int sl = slot - j + rel + back * kG;
+                        const int gen = (t - 1 - back + 2 * kGens) % kGens;
+                        const float4 qv = *reinterpret_cast<const float4*>(x_ola(sl, gen) + (i - 1) * kOlaQuarter + 4 * lq);
+                        if (i == 3) { o[0] = qv.x; o[1] = qv.y; o[2] = qv.z; o[3] = qv.w; }
+                        else { o[0] += qv.x; o[1] += qv.y; o[2] += qv.z; o[3] += qv.w; }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; i++) o[i] = (o[i] + y0[i]) * kGain;
+                    store_block(be, o);
+                }
+            }
+            pipe_barrier();                                   /*B*/  // R2 may overwrite the FFT input
+            had = active;
+            if (active) {
+                const int lb = pipe_lane(lane);
+                const FftLds L = make_fft_lds(S3, twa, w64, lb);
+                const cf* hw = reinterpret_cast<const cf*>(hann) + lb;
+                cf wn[8];                                     // synthesis window: requested behind the second transpose
+                fft512_pad_bc_g<kRich, !kRich>(zs, L, r_tb, hw, wn);
+                if (kRich) {
+#pragma unroll
+                    for (int r = 0; r < 8; r++) wn[r] = r_w[r];
+                }
                 // zs[r] = conj(z[n]) * 512 (x 4), n = lane + 64 r  ->  time samples 2n, 2n+1, windowed
                 float y[4][4];
 #pragma unroll
@@ -306,38 +533,22 @@ __global__ __launch_bounds__(kPipeThreads, 6) void pv_pipe_kernel(SigViewD src, 
                     y[r >> 1][2 * (r & 1)] = zs[r].x * w.x;
                     y[r >> 1][2 * (r & 1) + 1] = -(zs[r].y * w.y);   // the sign undoes the conjugation
                 }
-                float o[4];
+                if (kG == 1) {
+                    float o[4];
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    o[i] = (r0[i] + y[0][i]) * kGain;
-                    r0[i] = r1[i] + y[1][i];
-                    r1[i] = r2[i] + y[2][i];
-                    r2[i] = y[3][i];
-                }
-                const long long be = fz - 3;                  // wave-uniform: the block's base pointer stays scalar
-                if (be >= b0 && be < b_end && be * NAE_HOP < p.mid_len) {
-                    // buffer stores: scalar descriptor of the block + one 32-bit lane offset (plain pointer stores made hipcc
-                    // hoist four 64-bit per-lane addresses out of the frame loop: 8 VGPRs, spilled at 80)
-                    float* pb = optr + be * NAE_HOP * out.fs;
-                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(pb, 0, -1, 0x00020000);
-                    auto st = [&](unsigned byte_off, float v) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, (int)byte_off, 0, 0); };
-                    const unsigned fs4 = 4u * (unsigned)out.fs;                 // bytes between consecutive samples
-                    const unsigned oa = 2u * (unsigned)lane * fs4;              // sample 2 lane of the block
-                    if ((be + 1) * NAE_HOP <= p.mid_len) {
-                        if (out_vec) {
-                            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                            __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(o[0]), __float_as_uint(o[1])}, rs, (int)(8u * lane), 0, 0);
-                            __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(o[2]), __float_as_uint(o[3])}, rs, (int)(512u + 8u * lane), 0, 0);
-                        } else {
-                            st(oa, o[0]); st(oa + fs4, o[1]); st(oa + 128u * fs4, o[2]); st(oa + 129u * fs4, o[3]);
-                        }
-                    } else {
-                        const int rem = (int)(p.mid_len - be * NAE_HOP);
-                        if (2 * lane + 0 < rem) st(oa, o[0]);
-                        if (2 * lane + 1 < rem) st(oa + fs4, o[1]);
-                        if (128 + 2 * lane < rem) st(oa + 128u * fs4, o[2]);
-                        if (129 + 2 * lane < rem) st(oa + 129u * fs4, o[3]);
+                    for (int i = 0; i < 4; i++) {
+                        o[i] = (r0[i] + y[0][i]) * kGain;
+                        r0[i] = r1[i] + y[1][i];
+                        r1[i] = r2[i] + y[2][i];
+                        r2[i] = y[3][i];
                     }
+                    store_block(fz - 3, o);                   // wave-uniform: the block's base pointer stays scalar
+                } else {
+                    float* po = x_ola(slot, t % kGens) + 4 * lb;
+#pragma unroll
+                    for (int q = 1; q < 4; q++) *reinterpret_cast<float4*>(po + (q - 1) * kOlaQuarter) = float4{y[q][0], y[q][1], y[q][2], y[q][3]};
+#pragma unroll
+                    for (int i = 0; i < 4; i++) y0[i] = y[0][i];
                 }
             }
         }
@@ -348,24 +559,46 @@ __global__ __launch_bounds__(kPipeThreads, 6) void pv_pipe_kernel(SigViewD src, 
 
 using namespace nae;
 
-#ifdef NAE_PIPE_STAMPS
-extern "C" int nae_debug_read_pipe_stamps(unsigned long long* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_pipe_stamps), sizeof(unsigned long long) * 12 * 8 * 4); }
-extern "C" int nae_debug_read_pipe_total(unsigned long long* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_pipe_total), sizeof(unsigned long long) * 4 * 64); }
-#endif
+template <int kG, int kS, bool kRich>
+static void pipe_launch(nae_ctx* ctx, unsigned groups, const SigViewD& src, const PvParams& p, long long n_sc, const uint32_t* phase_ws,
+                        const OutViewD& out, const Tables& tb, bool unit_stride)
+{
+    // more than 64 KiB of dynamic LDS needs the attribute (once per instantiation)
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pv_pipe_kernel<true, kG, kS, kRich>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pipe_lds(kG, kS));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pv_pipe_kernel<false, kG, kS, kRich>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pipe_lds(kG, kS));
+        attr_done = true;
+    }
+    if (unit_stride)
+        NAE_KLAUNCH(ctx, "pv_synth_kernel", (pv_pipe_kernel<true, kG, kS, kRich>), dim3(groups), dim3(pipe_threads(kS)), pipe_lds(kG, kS), ctx->stream, src, p,
+                    n_sc, phase_ws, out, tb);
+    else
+        NAE_KLAUNCH(ctx, "pv_synth_kernel", (pv_pipe_kernel<false, kG, kS, kRich>), dim3(groups), dim3(pipe_threads(kS)), pipe_lds(kG, kS), ctx->stream, src, p,
+                    n_sc, phase_ws, out, tb);
+}
 
+// frames_per_step: 1 = one stream-channel per slot; 2 / 4 = frame-interleaved (two / one stream-channel per four slots)
 int nae_launch_pv_pipe(nae_ctx* ctx, const PvParams& p, const SigViewD& src, long long n_sc, const uint32_t* phase_ws,
-                       const OutViewD& out, bool unit_stride)
+                       const OutViewD& out, bool unit_stride, int frames_per_step)
 {
     const long long items = n_sc * p.n_tiles;
     if (items == 0) return NAE_OK;
-    const long long groups = (items + kPipeSc - 1) / kPipeSc;
+    if (frames_per_step != 1 && frames_per_step != 2 && frames_per_step != 4) return nae_fail(ctx, NAE_ERR_INVALID, "pv_pipe_kernel: frames per step");
+    // slots per workgroup: four, or two (eight-wave workgroups, four of them per CU, each at its own pace) with NAE_PIPE_SLOTS=2
+    const int slots = (frames_per_step == 1 && p.dbg0 == 2) ? 2 : 4;
+    const int units = slots / frames_per_step;
+    // stereo units come in channel pairs of one (stream, tile): n_sc is even, so items is
+    const long long groups = (items + units - 1) / units;
     if (groups > 0x7fffffffll) return nae_fail(ctx, NAE_ERR_INVALID, "pv_pipe_kernel: grid too large");
     Tables tb{ctx->d_w512, ctx->d_t1024, ctx->d_hann};
-    if (unit_stride)
-        NAE_KLAUNCH(ctx, "pv_synth_kernel", (pv_pipe_kernel<true>), dim3((unsigned)groups), dim3(kPipeThreads), kPipeLds, ctx->stream, src, p, n_sc,
-                    phase_ws, out, tb);
-    else
-        NAE_KLAUNCH(ctx, "pv_synth_kernel", (pv_pipe_kernel<false>), dim3((unsigned)groups), dim3(kPipeThreads), kPipeLds, ctx->stream, src, p, n_sc,
-                    phase_ws, out, tb);
+    // kRich: at most one workgroup per CU anyway (the frame-interleaved modes by their LDS; four slots per workgroup on a grid
+    // of at most n_cu workgroups) -> 128 VGPRs per wave, tables in registers
+    const bool rich1 = frames_per_step == 1 && slots == 4 && groups <= (long long)ctx->n_cu && p.dbg1 != 3;
+    if (frames_per_step == 1 && slots == 2) pipe_launch<1, 2, false>(ctx, (unsigned)groups, src, p, n_sc, phase_ws, out, tb, unit_stride);
+    else if (frames_per_step == 1 && rich1) pipe_launch<1, 4, true>(ctx, (unsigned)groups, src, p, n_sc, phase_ws, out, tb, unit_stride);
+    else if (frames_per_step == 1) pipe_launch<1, 4, false>(ctx, (unsigned)groups, src, p, n_sc, phase_ws, out, tb, unit_stride);
+    else if (frames_per_step == 2) pipe_launch<2, 4, true>(ctx, (unsigned)groups, src, p, n_sc, phase_ws, out, tb, unit_stride);
+    else pipe_launch<4, 4, true>(ctx, (unsigned)groups, src, p, n_sc, phase_ws, out, tb, unit_stride);
     return nae_check(ctx, hipGetLastError(), "pv_pipe_kernel");
 }

@@ -715,6 +715,8 @@ static PvParams make_pv_params(const nae_stretch_plan& pl, size_t in_len, int ch
     p.skip_from = p.n_tiles;
     p.phase_step = 1;
     p.phase_tiles = p.n_tiles;
+    p.dbg0 = getenv("NAE_PIPE_DBG0") ? atoi(getenv("NAE_PIPE_DBG0")) : 0;
+    p.dbg1 = getenv("NAE_PIPE_DBG1") ? atoi(getenv("NAE_PIPE_DBG1")) : 0;
     return p;
 }
 
@@ -780,14 +782,14 @@ int nae_launch_pv_phase(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig*
 
 int nae_launch_pv_synth(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig* src, size_t in_len, int ch,
                         size_t n_streams, int tile, int phase_tile, const uint32_t* phase_ws, const nae_sig* out,
-                        const nae_pv_segment* seg)
+                        const nae_pv_segment* seg, int frames_per_step)
 {
     if (phase_tile <= 0 || tile < phase_tile || tile % phase_tile) return nae_fail(ctx, NAE_ERR_INVALID, "phase tile must divide the synthesis tile");
     PvParams p = make_pv_params(*pl, in_len, ch, tile, seg);
     const long long cnt = p.f_stop - p.f_origin;
     p.phase_step = tile / phase_tile;
     p.phase_tiles = (int)((cnt + phase_tile - 1) / phase_tile);
-    return nae_launch_pv_pipe(ctx, p, to_view(src), (long long)n_streams * ch, phase_ws, to_out(out), src->frame_stride == 1);
+    return nae_launch_pv_pipe(ctx, p, to_view(src), (long long)n_streams * ch, phase_ws, to_out(out), src->frame_stride == 1, frames_per_step);
 }
 
 // outputs [j_begin, j_end)

@@ -143,23 +143,30 @@ int nae_ensure_rs_table(nae_ctx* ctx, double rate_eff)
     return NAE_OK;
 }
 
-// Tile lengths of the phase vocoder for a block call.  A synthesis tile is one unit of pass 3 (three waves,
-// kernels_pvpipe.hip); four of them make a workgroup and a CU holds two workgroups.  Every synthesis tile but the last of a
-// stream-channel is analysed twice (pass 1 sums its phase increments, pass 3 synthesises it), so synthesis tiles are as
-// long as parallelism allows: none at all once the stream-channels alone give every CU a workgroup (>= 1024 of them),
-// otherwise just enough for two workgroups per CU.  Pass 1 is one wave per tile and wants >= 4096 waves: it runs on tiles
-// `step` times shorter (*phase_tile), never shorter than 64 frames; the synthesis tile is a multiple of it.
-int nae_pick_pv_tile(nae_ctx* ctx, size_t frames, size_t n_sc, int* phase_tile)
+// Shape of the phase vocoder for a block call: frames per step of the pipeline (kernels_pvpipe.hip), synthesis tile, pass-1 tile.
+//   * >= 1024 stream-channels: four stream-channels per workgroup (frames_per_step 1), ONE tile per stream-channel — no
+//     pass 1, nothing analysed twice; from 2048 stream-channels two workgroups share a CU.
+//   * fewer: the four slots of a workgroup work on 2 or 4 consecutive frames of one stream-channel (frame-interleaved), so
+//     256 stream-channels (the 128 streams one rank of an 8-GPU job owns) still give every CU a workgroup without cutting
+//     a stream into time tiles.  A workgroup of these modes fills a CU's LDS alone: 4 frames per step up to n_cu
+//     stream-channels, 2 frames per step up to 2 n_cu.
+//   * fewer stream-channels than CUs: time tiles on top (each tile but the last of a stream-channel is analysed twice: pass 1
+//     sums its phase increments, pass 3 synthesises it), just enough of them for one workgroup per CU.  Pass 1 is one wave per
+//     tile and wants >= 4096 waves: it runs on tiles `step` times shorter (*phase_tile), never shorter than 64 frames; the
+//     synthesis tile is a multiple of it.
+int nae_pick_pv_shape(nae_ctx* ctx, size_t frames, size_t n_sc, int* phase_tile, int* frames_per_step)
 {
+    const size_t n_cu = (size_t)(ctx->n_cu > 0 ? ctx->n_cu : 256);
+    int fps = n_sc > 2 * n_cu ? 1 : n_sc > n_cu ? 2 : 4;
+    if (ctx->pv_fps == 1 || ctx->pv_fps == 2 || ctx->pv_fps == 4) fps = ctx->pv_fps;
+    *frames_per_step = fps;
     if (ctx->pv_tile > 0) { *phase_tile = ctx->pv_tile; return ctx->pv_tile; }
     *phase_tile = 64;
     if (frames == 0 || n_sc == 0) return 64;
     const size_t max_tiles = (frames + 63) / 64;
-    // synthesis tiles: two workgroups of four stream-channels per CU (2048 tiles) — except that from 512 stream-channels two
-    // tiles per stream-channel (one workgroup per CU) win: pass 1 then covers half of the frames instead of three quarters
-    // (measured at 256 streams: 4.46 against 4.60 ms per step; at 128 streams the same trade loses, 2.64 against 2.57)
-    const size_t target = n_sc >= 512 ? 1024 : 2048;
-    size_t n_synth = n_sc >= 1024 ? 1 : (target + n_sc - 1) / n_sc;
+    // workgroups wanted: one per CU (two from 2048 stream-channels, where no tiles are needed anyway)
+    const size_t wg = (n_sc * (size_t)fps + 3) / 4;                      // workgroups of one tile per stream-channel
+    size_t n_synth = wg >= n_cu ? 1 : n_cu / wg;
     if (n_synth > max_tiles) n_synth = max_tiles;
     size_t n_phase = n_synth == 1 ? 1 : (4096 + n_sc - 1) / n_sc;      // a single synthesis tile needs no pass 1
     if (n_phase > max_tiles) n_phase = max_tiles;
@@ -209,6 +216,7 @@ int nae_ctx_create(int device, nae_ctx** out)
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return NAE_ERR_HIP; }
     ctx->own_stream = true;
     if (const char* t = getenv("NAE_PV_TILE")) ctx->pv_tile = atoi(t) > 0 ? atoi(t) : 0;   // tuning knob (0 = automatic)
+    if (const char* t = getenv("NAE_PV_FPS")) ctx->pv_fps = atoi(t);
     ctx->dbg_rs_single = getenv("NAE_RS_SINGLE") != nullptr;
     ctx->dbg_no_mix_fuse = getenv("NAE_NO_MIX_FUSE") != nullptr;
     if (const char* e = getenv("NAE_TD_NC")) ctx->dbg_td_nc = atoi(e);
@@ -502,14 +510,14 @@ static int stretch_block_impl(nae_ctx* ctx, double rate, double pitch, const nae
     }
     if ((rc = run_mix())) return rc;     // vocoder first / transposer only: the mix is a launch of its own
     if (pl.pv_on) {
-        int phase_tile = 0;
-        const int tile = nae_pick_pv_tile(ctx, pl.frames, n_streams * ch, &phase_tile);
+        int phase_tile = 0, fps = 1;
+        const int tile = nae_pick_pv_shape(ctx, pl.frames, n_streams * ch, &phase_tile, &fps);
         rc = nae_ws_reserve(ctx, &ctx->ws_phase, &ctx->ws_phase_bytes, nae_pv_phase_workspace_bytes(pl.frames, ch, n_streams, phase_tile));
         if (rc) return rc;
         nae_pv_segment seg{0, (long long)pl.frames, (long long)pl.frames, pv_out_len, nullptr, nullptr};
         rc = nae_launch_pv_phase(ctx, &pl, pv_src, pv_in_len, ch, n_streams, phase_tile, tile, static_cast<uint32_t*>(ctx->ws_phase), &seg);
         if (rc) return rc;
-        rc = nae_launch_pv_synth(ctx, &pl, pv_src, pv_in_len, ch, n_streams, tile, phase_tile, static_cast<const uint32_t*>(ctx->ws_phase), pv_dst, &seg);
+        rc = nae_launch_pv_synth(ctx, &pl, pv_src, pv_in_len, ch, n_streams, tile, phase_tile, static_cast<const uint32_t*>(ctx->ws_phase), pv_dst, &seg, fps);
         if (rc) return rc;
     }
     if (pl.rs_on && !pl.rs_first) {

@@ -26,7 +26,8 @@ struct nae_ctx {
     float* d_rs_tab = nullptr; double rs_tab_rate = 0.0;
     std::vector<float> h_rs_tab;
     struct nae_wsola_cache* wsola_cache = nullptr;   // plan + workspaces of nae_wsola_block_f32 (nae_wsola.hip)
-    int pv_tile = 0;             // frames per phase-vocoder tile; 0 = choose per call (nae_pick_pv_tile)
+    int pv_tile = 0;             // frames per phase-vocoder tile; 0 = choose per call (nae_pick_pv_shape)
+    int pv_fps = 0;              // NAE_PV_FPS=1|2|4: frames per step of the vocoder pipeline (0 = choose per call)
     // tuning / A-B switches, read once from the environment at context creation (tools/ab.sh)
     bool dbg_st_unfused = false;     // NAE_ST_UNFUSED: WSOLA chain runs filter and cubic stage as separate launches
     int dbg_td_nc = 0;               // NAE_TD_NC=1|2|4: candidates per thread of the WSOLA search (0: by batch size)
@@ -77,13 +78,13 @@ int nae_launch_pv_phase(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig*
                         size_t n_streams, int tile, int synth_tile, uint32_t* phase_ws, const nae_pv_segment* seg);
 int nae_launch_pv_synth(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig* src, size_t in_len, int ch,
                         size_t n_streams, int tile, int phase_tile, const uint32_t* phase_ws, const nae_sig* out,
-                        const nae_pv_segment* seg);
+                        const nae_pv_segment* seg, int frames_per_step);
 int nae_launch_resample(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig* src, size_t src_len, int ch,
                         size_t n_streams, const float* d_tab, const nae_sig* out, size_t j_begin, size_t j_end);
 int nae_launch_mix_resample(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig* a, const nae_sig* b, float va, float vb,
                             const nae_sig* mix_out, size_t S, size_t n_streams, const float* d_tab, const nae_sig* out);
 int nae_ensure_rs_table(nae_ctx* ctx, double rate_eff);
-int nae_pick_pv_tile(nae_ctx* ctx, size_t frames, size_t n_sc, int* phase_tile);
+int nae_pick_pv_shape(nae_ctx* ctx, size_t frames, size_t n_sc, int* phase_tile, int* frames_per_step);
 constexpr int kPhasePad = 520; // int32 per (stream-channel, tile) record in the phase workspace
 
 // nae_wsola.hip

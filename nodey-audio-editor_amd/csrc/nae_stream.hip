@@ -137,7 +137,7 @@ int stretch_process(nae_stretch* h)
             nae_sig dst{h->out.cur.p - (ptrdiff_t)h->out.base * ch, 0, 1, (size_t)ch};
             rc = nae_launch_pv_phase(ctx, &pl, &src, h->mid_total, ch, 1, tile, tile, static_cast<uint32_t*>(ctx->ws_phase), &seg);
             if (rc) return rc;
-            rc = nae_launch_pv_synth(ctx, &pl, &src, h->mid_total, ch, 1, tile, tile, static_cast<const uint32_t*>(ctx->ws_phase), &dst, &seg);
+            rc = nae_launch_pv_synth(ctx, &pl, &src, h->mid_total, ch, 1, tile, tile, static_cast<const uint32_t*>(ctx->ws_phase), &dst, &seg, 1);
             if (rc) return rc;
             h->carry_cur ^= 1;
             h->blocks_done = B_r;
@@ -203,7 +203,7 @@ int stretch_process(nae_stretch* h)
             }
             rc = nae_launch_pv_phase(ctx, &pl, &src, h->in_total, ch, 1, tile, tile, static_cast<uint32_t*>(ctx->ws_phase), &seg);
             if (rc) return rc;
-            rc = nae_launch_pv_synth(ctx, &pl, &src, h->in_total, ch, 1, tile, tile, static_cast<const uint32_t*>(ctx->ws_phase), &dst, &seg);
+            rc = nae_launch_pv_synth(ctx, &pl, &src, h->in_total, ch, 1, tile, tile, static_cast<const uint32_t*>(ctx->ws_phase), &dst, &seg, 1);
             if (rc) return rc;
             h->carry_cur ^= 1;
             h->blocks_done = B_r;

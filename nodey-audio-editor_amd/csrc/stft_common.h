@@ -30,6 +30,7 @@ struct PvParams {
     int skip_from;        // pass 1 only: tiles >= skip_from are not analysed (their sums are not needed)
     int phase_step;       // pass 3 only: pass 1 ran on tiles `phase_step` times shorter (more waves for the same frames);
     int phase_tiles;      //              the base phase of tile t is record t * phase_step of `phase_tiles` per stream-channel
+    int dbg0, dbg1;       // experiment knobs (NAE_PIPE_DBG0 / NAE_PIPE_DBG1), 0 in production
 };
 
 __device__ __forceinline__ long long frame_start(const PvParams& p, long long f)
@@ -65,4 +66,4 @@ __device__ __forceinline__ void phase_inc(const uint32_t (&qa)[9], const uint32_
 
 // kernels_pvpipe.hip
 int nae_launch_pv_pipe(nae_ctx* ctx, const nae::PvParams& p, const nae::SigViewD& src, long long n_sc, const uint32_t* phase_ws,
-                       const nae::OutViewD& out, bool unit_stride);
+                       const nae::OutViewD& out, bool unit_stride, int frames_per_step);

@@ -158,30 +158,37 @@ void orc_irfft1024(const float* X, float* y)
     irfft1024((const cf*)X, y);
 }
 
-/* canonical atan2 in turns, quantised to Q0.32 (wrapping) */
+/* canonical atan2 in turns, quantised to Q0.32 (wrapping): include/nae_dsp_spec.h, revision 2 — reciprocal by an integer
+ * seed and three Newton steps (fma only), octants by integer reflections that follow the sign bits */
+static uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 int32_t orc_atan2_q32(float im, float re)
 {
     const float ax = fabsf(re), ay = fabsf(im);
-    const float mx = ax > ay ? ax : ay;
+    if (!((ax + ay) < INFINITY)) return 0;                /* a non-finite bin (NaN, Inf, or a sum that overflows) has phase 0 */
+    float mx = ax > ay ? ax : ay;
+    if (!(mx > NAE_ATAN_TINY)) mx = NAE_ATAN_TINY;
     const float mn = ax > ay ? ay : ax;
-    if (!(mx > 0.0f)) return 0;
-    const float t = mn / mx;
+    float r = u2f(NAE_RCP_MAGIC - f2u(mx));
+    for (int it = 0; it < 3; it++) {
+        const float e = fmaf(-mx, r, 1.0f);
+        r = fmaf(r, e, r);
+    }
+    const float t = mn * r;
     const float s = t * t;
-    float q = NAE_ATAN_C6;
-    q = fmaf(q, s, NAE_ATAN_C5);
-    q = fmaf(q, s, NAE_ATAN_C4);
-    q = fmaf(q, s, NAE_ATAN_C3);
-    q = fmaf(q, s, NAE_ATAN_C2);
-    q = fmaf(q, s, NAE_ATAN_C1);
-    q = fmaf(q, s, NAE_ATAN_C0);
-    float p = q * t;
-    if (ay > ax) p = 0.25f - p;
-    if (re < 0.0f) p = 0.5f - p;
-    if (im < 0.0f) p = -p;
-    /* turns -> Q0.32, round to nearest, SATURATING: exactly half a turn (p = +0.5) becomes 0x7fffffff, one unit below
-     * the wrapping value; the conversion is then a single saturating float->int instruction on the GPU */
-    const float f = rintf(p * 4294967296.0f);
-    return (f >= 2147483648.0f) ? INT32_MAX : (int32_t)f;
+    float q = NAE_ATAN_C6 * NAE_ATAN_SCALE;
+    q = fmaf(q, s, NAE_ATAN_C5 * NAE_ATAN_SCALE);
+    q = fmaf(q, s, NAE_ATAN_C4 * NAE_ATAN_SCALE);
+    q = fmaf(q, s, NAE_ATAN_C3 * NAE_ATAN_SCALE);
+    q = fmaf(q, s, NAE_ATAN_C2 * NAE_ATAN_SCALE);
+    q = fmaf(q, s, NAE_ATAN_C1 * NAE_ATAN_SCALE);
+    q = fmaf(q, s, NAE_ATAN_C0 * NAE_ATAN_SCALE);
+    uint32_t i = (uint32_t)(int32_t)rintf(q * t);
+    if (ay > ax) i = 0x40000000u - i;
+    const uint32_t m_re = (f2u(re) >> 31) ? 0xffffffffu : 0u, m_im = (f2u(im) >> 31) ? 0xffffffffu : 0u;
+    i = (i ^ m_re) + (m_re & 0x80000001u);
+    i = (i ^ m_im) - m_im;
+    return (int32_t)i;
 }
 
 /* ------------------------------------------------------------------------------------------ K8 */

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
-"""Diagnostic (variant build -DNAE_PIPE_STAMPS, never shipped): per-wave s_memtime stamps around the two barriers of eight
-steps of pv_pipe_kernel, workgroup 0, while the C5 graph runs.  Build: tools/mkvariant.sh stamps -DNAE_PIPE_STAMPS
-Run:   NAE_GPU_LIB=nodey-audio-editor_amd/variants/libnae_gpu_stamps.so python tools/pipe_stamps.py [n_streams]   (512: one workgroup per CU)"""
+"""Diagnostic (variant build, never shipped): per-wave s_memtime stamps around the two barriers of eight steps of
+pv_pipe_kernel, workgroup 0, while the C5 graph runs.  Build: tools/pipe_stamps/make_variant.sh (a stamped COPY of the kernel source)
+Run:   NAE_GPU_LIB=nodey-audio-editor_amd/variants/libnae_gpu_stamps.so python tools/pipe_stamps/pipe_stamps.py [n_streams]   (512: one workgroup per CU)"""
 import collections
 import ctypes as C
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import naeload
@@ -33,20 +33,20 @@ g.S, g.n_streams = S, n_streams
 for _ in range(3):
     ctx.graph4(g)
 ctx.sync()
-st = np.zeros(12 * 8 * 4, np.uint64)
+st = np.zeros(16 * 8 * 4, np.uint64)
 rc = ctx.lib.nae_debug_read_pipe_stamps(st.ctypes.data_as(C.c_void_p))
 assert rc == 0, rc
-st = st.reshape(12, 8, 4).astype(np.int64)
+st = st.reshape(16, 8, 4).astype(np.int64)
 t0 = st[:, 0, 0].min()
 st -= t0
-names = ["R1"] * 4 + ["R2"] * 4 + ["R3"] * 4
+names = ["R1 "] * 4 + ["R2a"] * 4 + ["R2b"] * 4 + ["R3 "] * 4
 print("cycles relative to the first stamp; per wave and step: arrive A, leave A, arrive B, leave B")
 for step in range(8):
     print(f"-- step {200 + step}")
-    for w in range(12):
+    for w in range(16):
         a0, a1, b0, b1 = st[w, step]
         nxt = st[w, step + 1, 0] if step < 7 else -1
-        print(f"  wave {w:2d} {names[w]} sc{w % 4}: A {a0:7d} -> {a1:7d} (wait {a1 - a0:5d}) | alpha {b0 - a1:5d} | B {b0:7d} -> {b1:7d} (wait {b1 - b0:5d}) | beta {nxt - b1 if nxt >= 0 else -1:5d}")
+        print(f"  wave {w:2d} {names[w]} slot{w % 4}: A {a0:7d} -> {a1:7d} (wait {a1 - a0:5d}) | alpha {b0 - a1:5d} | B {b0:7d} -> {b1:7d} (wait {b1 - b0:5d}) | beta {nxt - b1 if nxt >= 0 else -1:5d}")
 per_step = (st[:, 7, 0] - st[:, 0, 0]) / 7.0
 print("cycles per step per wave:", np.round(per_step).astype(int))
 tot = np.zeros(4 * 64, np.uint64)
