@@ -48,7 +48,7 @@ constexpr int pipe_ola_gens(int kG) { return kG >= 3 ? 2 : 3; }
 constexpr int kOlaQuarter = 256;                            // floats
 constexpr size_t pipe_lds_x_per_slot(int kG) { return kG == 1 ? 0 : 3 * kPhasePad * sizeof(uint32_t) + (size_t)pipe_ola_gens(kG) * 3 * kOlaQuarter * sizeof(float); }
 constexpr size_t pipe_lds(int kG, int kS) { return kPipeLdsTables + kS * (kPipeLdsPerSlot + pipe_lds_x_per_slot(kG)); }
-static_assert(2 * pipe_lds(1, 4) <= 160 * 1024 && 4 * pipe_lds(1, 2) <= 160 * 1024, "two / four workgroups per CU");
+static_assert(2 * pipe_lds(1, 4) <= 160 * 1024, "two workgroups per CU");
 static_assert(pipe_lds(2, 4) <= 160 * 1024 && pipe_lds(4, 4) <= 160 * 1024, "one workgroup per CU");
 
 // every LDS operation of this wave has completed, then the workgroup barrier (vector-memory operations stay in flight:
@@ -59,13 +59,14 @@ __device__ __forceinline__ void pipe_barrier() { asm volatile("s_waitcnt lgkmcnt
 // arrived first runs its steps faster than its neighbour on every CU (profiles/r02_pipe_stamps_per_cu.txt).  They take turns: a
 // workgroup learns whether it was the first or the second on its CU (g_cu_arrivals, counted per physical CU, never reset: only
 // the parity is used) and raises its priority on alternate steps; the role that ends a step's critical path (R3) sits one
-// level above its workgroup's.  (Measured and dropped: keeping the pair level by feedback — each workgroup publishing its step
-// counter, whoever is behind at the higher priority — levels them at the pace of the SLOWER one: 7.8 against 7.3 ms.)
+// level above its workgroup's (6.80 ms against 6.85 without and 7.00 with the phase role R2b up there instead, one box).
+// Measured and dropped: keeping the pair level by feedback — each workgroup publishing its step counter, whoever is behind at the
+// higher priority — levels them at the pace of the SLOWER one (7.8 against 7.3 ms); static priorities by role; two-slot
+// (eight-wave) workgroups, four per CU, each at its own pace (within 1 %).
 __device__ unsigned g_cu_arrivals[8 * 4 * 16];
-__device__ __forceinline__ void pipe_prio(int t, int slot, int role, int mode)
+__device__ __forceinline__ void pipe_prio(int t, int slot, int role)
 {
-    if (mode == 1) return;
-    const int lvl = (((t + slot) & 1) ? 2 : 0) + (role == 3 && mode != 2 ? 1 : 0);      // wave-uniform
+    const int lvl = (((t + slot) & 1) ? 2 : 0) + (role == 3 ? 1 : 0);                   // wave-uniform
     if (lvl == 0) __builtin_amdgcn_s_setprio(0);
     else if (lvl == 1) __builtin_amdgcn_s_setprio(1);
     else if (lvl == 2) __builtin_amdgcn_s_setprio(2);
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(pipe_threads(kS), kRich ? (kS == 4 ? 4 : 2) : 8) vo
         for (int t = 0; t < T; t++) {
             const bool cur = kG * t + j < n;
             pipe_barrier();                                   /*A*/
-            if (kG == 1) pipe_prio(t, prio_slot, role, p.dbg1);
+            if (kG == 1) pipe_prio(t, prio_slot, role);
             if (cur) {
                 // register-only part while R2 reads Z of the previous step out of this wave's scratch.  Window and pass-A
                 // twiddles are requested together (one LDS round trip): the accesses are volatile, so the compiler keeps them
@@ -227,65 +228,66 @@ __global__ __launch_bounds__(pipe_threads(kS), kRich ? (kS == 4 ? 4 : 2) : 8) vo
     } else if (role <= 2) {
         // ------------------------------------------------------------------------------------------ R2a / R2b: phases
         // Bins in mirror pairs: a lane owns k = lane + 64 (2 h + i) and 512 - k, i = 0, 1 (items 2 i and 2 i + 1) — 0..127 and
-        // 385..512 for h = 0, 128..255 and 257..384 for h = 1 — and h = 1 also owns the self-mirrored bin 256 (item 4, lane 0).
-        // One pair of reads (A = Z[k], B = Z[512 - k]) gives both spectra: the mirror's E and O are (Ex, -Ey) and (-Ox, Oy) —
-        // exact negations and commuted sums of the canonical formula, so every phase keeps its bits — and both rotated bins of a
-        // pair meet in one lane, where the c2r pre-twiddle of R3's FFT input needs them: what goes to R3 is that input, not Y.
+        // 385..512 for h = 0, 128..255 and 257..384 for h = 1.  One pair of reads (A = Z[k], B = Z[512 - k]) gives both spectra:
+        // the mirror's E and O are (Ex, -Ey) and (-Ox, Oy) — exact negations and commuted sums of the canonical formula, so
+        // every phase keeps its bits — and both rotated bins of a pair meet in one lane, where the c2r pre-twiddle of R3's FFT
+        // input needs them: what goes to R3 is that input, not Y.
+        // 513 bins are 512 items and one more.  The odd one is bin 512, whose phase is just the sign of a real number (no atan2):
+        // in lane 0 of h = 0 the pair would be (0, 512); there item 1 carries the self-mirrored bin 256 instead (its own A = B =
+        // Z[256]), and bin 512 rides along in that wave as a fifth, cheap item (sign, increment, one cosine).
         const int h = role - 1;
-        const int k0 = lane + 128 * h;                        // items 0 / 2: k0, k0 + 64; items 1 / 3: 512 - k0, 448 - k0
-        const bool pair0_is_dc = (h == 0) && (lane == 0);     // the pair (0, 512): both real; bin 512's phase is its sign
-        cf tk[2], tm[2];                                      // split twiddles of the pair's bins (loop-invariant: 8 VGPRs)
+        const int k0 = lane + 128 * h;                        // items 0 / 2: k0, k0 + 64; items 1 / 3: 512 - k0 (256 in lane 0 of h = 0), 448 - k0
+        const bool dc = (h == 0) && (lane == 0);              // the lane of bins 0, 256 and 512
+        const int km0 = dc ? 256 : 512 - k0;                  // bin of item 1
+        cf tk[2], tm[2];                                      // split twiddles of the items' bins (loop-invariant: 8 VGPRs)
 #pragma unroll
-        for (int i = 0; i < 2; i++) { tk[i] = tb.t1024[k0 + 64 * i]; tm[i] = tb.t1024[512 - k0 - 64 * i]; }
-        const cf t256 = tb.t1024[256];
-        uint32_t qs[5], qp[5];
+        for (int i = 0; i < 2; i++) { tk[i] = tb.t1024[k0 + 64 * i]; tm[i] = tb.t1024[i == 0 ? km0 : 448 - k0]; }
+        const cf tms = tb.t1024[512 - k0];                    // split twiddle of the pair's mirror (differs from tm[0] in lane 0 of h = 0: bin 512)
+        uint32_t qs[5], qp[5];                                // [4]: bin 512 (h = 0)
         {
             const uint32_t* bp = base_phase + (sc * p.phase_tiles + (long long)tile * p.phase_step) * kT1024Pad;
-#pragma unroll
-            for (int i = 0; i < 2; i++) { qs[2 * i] = bp[k0 + 64 * i]; qs[2 * i + 1] = bp[512 - k0 - 64 * i]; }
-            qs[4] = bp[256];
+            qs[0] = bp[k0]; qs[1] = bp[km0]; qs[2] = bp[k0 + 64]; qs[3] = bp[448 - k0];
+            qs[4] = bp[512];
 #pragma unroll
             for (int q = 0; q < 5; q++) qp[q] = 0;
         }
-        cf hx[5];                                             // kG > 1: the frame analysed in the previous step
+        cf hx[5];                                             // kG > 1: the frame analysed in the previous step ([4]: bin 512)
         uint32_t hqa[5] = {0, 0, 0, 0, 0};
 #pragma unroll
         for (int q = 0; q < 5; q++) hx[q] = cf{0.0f, 0.0f};
-        // phase increment of all items of this lane (exact integers); the mirror's k d mod 1024 follows from the bin's
+        // phase increment of all items of this lane (exact integers)
         auto inc_items = [&](const uint32_t (&qa)[5], const uint32_t (&qv)[5], unsigned d, unsigned R, uint32_t (&inc)[5]) {
-            const int kk = pipe_lane(k0);
-#pragma unroll
-            for (int i = 0; i < 2; i++) {
-                inc[2 * i] = pipe_inc(qa[2 * i], qv[2 * i], (unsigned)(kk + 64 * i), d, R);
-                inc[2 * i + 1] = pipe_inc(qa[2 * i + 1], qv[2 * i + 1], (unsigned)(512 - kk - 64 * i), d, R);
-            }
-            inc[4] = (h == 1) ? pipe_inc(qa[4], qv[4], 256u, d, R) : 0u;
+            const int kk = pipe_lane(k0), km = pipe_lane(km0);
+            inc[0] = pipe_inc(qa[0], qv[0], (unsigned)kk, d, R);
+            inc[1] = pipe_inc(qa[1], qv[1], (unsigned)km, d, R);
+            inc[2] = pipe_inc(qa[2], qv[2], (unsigned)(kk + 64), d, R);
+            inc[3] = pipe_inc(qa[3], qv[3], (unsigned)(448 - kk), d, R);
+            inc[4] = (h == 0) ? pipe_inc(qa[4], qv[4], 512u, d, R) : 0u;
         };
         // rotation by the phase difference and the in-lane c2r pre-twiddle: R3's FFT input Zin[k], Zin[512 - k]
         // (conjugated, inverse = conj(FFT(conj Z)) / 512; 2E, 2D: see kGain)
         auto synth_items = [&](const cf (&x)[5], const uint32_t (&qsv)[5], const uint32_t (&qav)[5]) {
-            const int kk = pipe_lane(k0);
+            const int kk = pipe_lane(k0), km = pipe_lane(km0);
             cf* Yk = Y + kk;
-            cf* Ym = Y + 512 - kk;
 #pragma unroll
             for (int i = 0; i < 2; i++) {
                 cf yk = pipe_rotate(x[2 * i], qsv[2 * i], qav[2 * i]);
-                cf ym = pipe_rotate(x[2 * i + 1], qsv[2 * i + 1], qav[2 * i + 1]);
-                if (i == 0 && pair0_is_dc) { yk.y = 0.0f; ym.y = 0.0f; }     // c2r ignores Im Y[0] and Im Y[512]
-                const cf E{yk.x + ym.x, yk.y - ym.y};
-                const cf D{yk.x - ym.x, yk.y + ym.y};
+                const cf ym = pipe_rotate(x[2 * i + 1], qsv[2 * i + 1], qav[2 * i + 1]);
+                cf a = ym, b = yk;                            // index 512 - k: the roles of the two bins swap
+                cf mk = ym;                                   // the partner of bin k
+                if (i == 0 && h == 0) {
+                    // lane 0: bin 0 pairs with bin 512 (both real: c2r ignores their imaginary parts), bin 256 with itself
+                    const float y512 = pipe_rotate(x[4], qsv[4], qav[4]).x;
+                    if (dc) { yk.y = 0.0f; mk = cf{y512, 0.0f}; b = ym; }
+                }
+                const cf E{yk.x + mk.x, yk.y - mk.y};
+                const cf D{yk.x - mk.x, yk.y + mk.y};
                 const cf Q{__builtin_fmaf(tk[i].x, D.x, tk[i].y * D.y), __builtin_fmaf(tk[i].x, D.y, -(tk[i].y * D.x))};
                 lds_st(Yk + 64 * i, cf{E.x - Q.y, -(E.y + Q.x)});
-                // index 512 - k: the roles of the two bins swap
-                const cf Qm{__builtin_fmaf(tm[i].x, -D.x, tm[i].y * D.y), __builtin_fmaf(tm[i].x, D.y, tm[i].y * D.x)};
-                if (!(i == 0 && pair0_is_dc)) lds_st(Ym - 64 * i, cf{E.x - Qm.y, E.y - Qm.x});
-            }
-            if (h == 1 && lane == 0) {
-                const cf y = pipe_rotate(x[4], qsv[4], qav[4]);
-                const cf E{y.x + y.x, y.y - y.y};
-                const cf D{y.x - y.x, y.y + y.y};
-                const cf Q{__builtin_fmaf(t256.x, D.x, t256.y * D.y), __builtin_fmaf(t256.x, D.y, -(t256.y * D.x))};
-                Y[256] = cf{E.x - Q.y, -(E.y + Q.x)};
+                const cf Em{a.x + b.x, a.y - b.y};
+                const cf Dm{a.x - b.x, a.y + b.y};
+                const cf Qm{__builtin_fmaf(tm[i].x, Dm.x, tm[i].y * Dm.y), __builtin_fmaf(tm[i].x, Dm.y, -(tm[i].y * Dm.x))};
+                lds_st(Y + (i == 0 ? km : 448 - kk), cf{Em.x - Qm.y, -(Em.y + Qm.x)});
             }
         };
 #pragma unroll 1
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(pipe_threads(kS), kRich ? (kS == 4 ? 4 : 2) : 8) vo
             const bool act_b = kG > 1 && t >= 2 && ib < n;
             const long long fb = f_first + ib;
             pipe_barrier();                                   /*A*/  // Z of frame fa is complete
-            if (kG == 1) pipe_prio(t, prio_slot, role, p.dbg1);
+            if (kG == 1) pipe_prio(t, prio_slot, role);
             cf va[5];
             if (act_a) {
                 const int kk = pipe_lane(k0);
@@ -307,7 +309,7 @@ __global__ __launch_bounds__(pipe_threads(kS), kRich ? (kS == 4 ? 4 : 2) : 8) vo
 #pragma unroll
                 for (int i = 0; i < 2; i++) { A[i] = lds_ld(Zk + 64 * i); B[i] = lds_ld(Zm - 64 * i); }
                 cf z256{0.0f, 0.0f};
-                if (h == 1) z256 = lds_ld(S1 + 256);
+                if (h == 0) z256 = lds_ld(S1 + 256);
                 // r2c split -> 2 X (phases are scale-invariant; the factor is undone in R3's output gain: a factor 2 is
                 // exact in every product on the way)
 #pragma unroll
@@ -318,21 +320,24 @@ __global__ __launch_bounds__(pipe_threads(kS), kRich ? (kS == 4 ? 4 : 2) : 8) vo
                     va[2 * i] = cf{E.x + P.y, E.y - P.x};
                     const cf Em = cf{E.x, -E.y};
                     const cf Om = cf{-O.x, O.y};
-                    const cf Pm = cmul_tw(Om, tm[i]);
+                    const cf Pm = cmul_tw(Om, i == 0 ? tms : tm[i]);
                     va[2 * i + 1] = cf{Em.x + Pm.y, Em.y - Pm.x};
                 }
-                {
+                va[4] = cf{0.0f, 0.0f};
+                if (h == 0) {
+                    // lane 0: item 1 so far is bin 512 (from Z[0] alone) -> the fifth item; bin 256 takes its place
+                    va[4] = va[1];
                     const cf E = cf{z256.x + z256.x, z256.y - z256.y};
                     const cf O = cf{z256.x - z256.x, z256.y + z256.y};
-                    const cf P = cmul_tw(O, t256);
-                    va[4] = cf{E.x + P.y, E.y - P.x};
+                    const cf P = cmul_tw(O, tm[0]);
+                    if (dc) va[1] = cf{E.x + P.y, E.y - P.x};
                 }
             }
             if (kG > 1) {
                 // increment of the held frame fb: its predecessor's analysis phases were left in LDS one step ago (slot j-1), or
                 // two steps ago by the last slot (j = 0)
                 uint32_t inc[5] = {0, 0, 0, 0, 0};
-                const int kk = pipe_lane(k0);
+                const int kk = pipe_lane(k0), km = pipe_lane(km0);
                 if (act_b && fb >= b0) {
                     if (fb == 0) {
 #pragma unroll
@@ -340,27 +345,24 @@ __global__ __launch_bounds__(pipe_threads(kS), kRich ? (kS == 4 ? 4 : 2) : 8) vo
                     } else {
                         const uint32_t* pq = j > 0 ? x_qa(slot - 1, (t - 1) & 1) : x_qa(slot + kG - 1, t & 1);
                         uint32_t pv[5];
-#pragma unroll
-                        for (int i = 0; i < 2; i++) { pv[2 * i] = pq[kk + 64 * i]; pv[2 * i + 1] = pq[512 - kk - 64 * i]; }
-                        pv[4] = pq[256];
+                        pv[0] = pq[kk]; pv[1] = pq[km]; pv[2] = pq[kk + 64]; pv[3] = pq[448 - kk];
+                        pv[4] = pq[512];
                         const unsigned d = (unsigned)(frame_start(p, fb) - frame_start(p, fb - 1));
                         const unsigned R = (d == (unsigned)p.d0) ? p.r_q24_0 : p.r_q24_1;
                         inc_items(hqa, pv, d, R, inc);
                     }
                 }
                 uint32_t* pi = x_inc(slot);
-#pragma unroll
-                for (int i = 0; i < 2; i++) { pi[kk + 64 * i] = inc[2 * i]; pi[512 - kk - 64 * i] = inc[2 * i + 1]; }
-                if (h == 1 && lane == 0) pi[256] = inc[4];
+                pi[kk] = inc[0]; pi[km] = inc[1]; pi[kk + 64] = inc[2]; pi[448 - kk] = inc[3];
+                if (dc) pi[512] = inc[4];
             }
             pipe_barrier();                                   /*B*/  // R1 may overwrite its scratch
             uint32_t qa[5] = {0, 0, 0, 0, 0};
             if (act_a) {
 #pragma unroll
                 for (int q = 0; q < 4; q++) qa[q] = atan2_q32(va[q].y, va[q].x);
-                if (h == 1) qa[4] = atan2_q32(va[4].y, va[4].x);
                 // bin N/2 of a real signal is real: its phase is 0 or 1/2 turn by the sign of the real part
-                if (pair0_is_dc) qa[1] = (va[1].x < 0.0f) ? 0x80000000u : 0u;
+                if (h == 0) qa[4] = (va[4].x < 0.0f) ? 0x80000000u : 0u;
             }
             if (kG == 1) {
                 if (act_a) {
@@ -383,15 +385,14 @@ __global__ __launch_bounds__(pipe_threads(kS), kRich ? (kS == 4 ? 4 : 2) : 8) vo
                 }
             } else {
                 if (act_a) {
-                    const int kk = pipe_lane(k0);
+                    const int kk = pipe_lane(k0), km = pipe_lane(km0);
                     uint32_t* pq = x_qa(slot, t & 1);
-#pragma unroll
-                    for (int i = 0; i < 2; i++) { pq[kk + 64 * i] = qa[2 * i]; pq[512 - kk - 64 * i] = qa[2 * i + 1]; }
-                    if (h == 1 && lane == 0) pq[256] = qa[4];
+                    pq[kk] = qa[0]; pq[km] = qa[1]; pq[kk + 64] = qa[2]; pq[448 - kk] = qa[3];
+                    if (dc) pq[512] = qa[4];
                 }
                 if (act_b) {
                     // running phase: the increments of the unit's slots up to this one; all of them move the base on
-                    const int kk = pipe_lane(k0);
+                    const int kk = pipe_lane(k0), km = pipe_lane(km0);
                     uint32_t mine[5], base[5];
 #pragma unroll
                     for (int q = 0; q < 5; q++) { mine[q] = qs[q]; base[q] = qs[q]; }
@@ -399,9 +400,8 @@ __global__ __launch_bounds__(pipe_threads(kS), kRich ? (kS == 4 ? 4 : 2) : 8) vo
                     for (int i2 = 0; i2 < kG; i2++) {
                         const uint32_t* pi = x_inc(slot - j + i2);
                         uint32_t v[5];
-#pragma unroll
-                        for (int i = 0; i < 2; i++) { v[2 * i] = pi[kk + 64 * i]; v[2 * i + 1] = pi[512 - kk - 64 * i]; }
-                        v[4] = pi[256];
+                        v[0] = pi[kk]; v[1] = pi[km]; v[2] = pi[kk + 64]; v[3] = pi[448 - kk];
+                        v[4] = pi[512];
 #pragma unroll
                         for (int q = 0; q < 5; q++) {
                             base[q] += v[q];
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(pipe_threads(kS), kRich ? (kS == 4 ? 4 : 2) : 8) vo
             const long long fz = f_first + iz;
             const bool active = iz >= 0 && iz < n && fz >= b0;
             pipe_barrier();                                   /*A*/  // the FFT input of frame fz is complete
-            if (kG == 1) pipe_prio(t, prio_slot, role, p.dbg1);
+            if (kG == 1) pipe_prio(t, prio_slot, role);
             cf zs[8];
             if (active) {
                 // FFT input and pass-A twiddles in one round trip; pass A is register-only, so it runs on this side of barrier B
@@ -585,8 +585,7 @@ int nae_launch_pv_pipe(nae_ctx* ctx, const PvParams& p, const SigViewD& src, lon
     const long long items = n_sc * p.n_tiles;
     if (items == 0) return NAE_OK;
     if (frames_per_step != 1 && frames_per_step != 2 && frames_per_step != 4) return nae_fail(ctx, NAE_ERR_INVALID, "pv_pipe_kernel: frames per step");
-    // slots per workgroup: four, or two (eight-wave workgroups, four of them per CU, each at its own pace) with NAE_PIPE_SLOTS=2
-    const int slots = (frames_per_step == 1 && p.dbg0 == 2) ? 2 : 4;
+    const int slots = 4;
     const int units = slots / frames_per_step;
     // stereo units come in channel pairs of one (stream, tile): n_sc is even, so items is
     const long long groups = (items + units - 1) / units;
@@ -594,9 +593,8 @@ int nae_launch_pv_pipe(nae_ctx* ctx, const PvParams& p, const SigViewD& src, lon
     Tables tb{ctx->d_w512, ctx->d_t1024, ctx->d_hann};
     // kRich: at most one workgroup per CU anyway (the frame-interleaved modes by their LDS; four slots per workgroup on a grid
     // of at most n_cu workgroups) -> 128 VGPRs per wave, tables in registers
-    const bool rich1 = frames_per_step == 1 && slots == 4 && groups <= (long long)ctx->n_cu && p.dbg1 != 3;
-    if (frames_per_step == 1 && slots == 2) pipe_launch<1, 2, false>(ctx, (unsigned)groups, src, p, n_sc, phase_ws, out, tb, unit_stride);
-    else if (frames_per_step == 1 && rich1) pipe_launch<1, 4, true>(ctx, (unsigned)groups, src, p, n_sc, phase_ws, out, tb, unit_stride);
+    const bool rich1 = frames_per_step == 1 && groups <= (long long)ctx->n_cu;
+    if (frames_per_step == 1 && rich1) pipe_launch<1, 4, true>(ctx, (unsigned)groups, src, p, n_sc, phase_ws, out, tb, unit_stride);
     else if (frames_per_step == 1) pipe_launch<1, 4, false>(ctx, (unsigned)groups, src, p, n_sc, phase_ws, out, tb, unit_stride);
     else if (frames_per_step == 2) pipe_launch<2, 4, true>(ctx, (unsigned)groups, src, p, n_sc, phase_ws, out, tb, unit_stride);
     else pipe_launch<4, 4, true>(ctx, (unsigned)groups, src, p, n_sc, phase_ws, out, tb, unit_stride);

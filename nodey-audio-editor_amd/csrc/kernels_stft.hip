@@ -715,8 +715,6 @@ static PvParams make_pv_params(const nae_stretch_plan& pl, size_t in_len, int ch
     p.skip_from = p.n_tiles;
     p.phase_step = 1;
     p.phase_tiles = p.n_tiles;
-    p.dbg0 = getenv("NAE_PIPE_DBG0") ? atoi(getenv("NAE_PIPE_DBG0")) : 0;
-    p.dbg1 = getenv("NAE_PIPE_DBG1") ? atoi(getenv("NAE_PIPE_DBG1")) : 0;
     return p;
 }
 

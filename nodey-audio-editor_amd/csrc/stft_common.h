@@ -30,7 +30,6 @@ struct PvParams {
     int skip_from;        // pass 1 only: tiles >= skip_from are not analysed (their sums are not needed)
     int phase_step;       // pass 3 only: pass 1 ran on tiles `phase_step` times shorter (more waves for the same frames);
     int phase_tiles;      //              the base phase of tile t is record t * phase_step of `phase_tiles` per stream-channel
-    int dbg0, dbg1;       // experiment knobs (NAE_PIPE_DBG0 / NAE_PIPE_DBG1), 0 in production
 };
 
 __device__ __forceinline__ long long frame_start(const PvParams& p, long long f)

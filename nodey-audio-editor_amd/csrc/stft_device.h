@@ -433,7 +433,8 @@ __device__ __forceinline__ uint32_t atan2_q32(float im, float re)
 {
     const float ax = __builtin_fabsf(re), ay = __builtin_fabsf(im);
     const float mx = __builtin_fmaxf(__builtin_fmaxf(ax, ay), NAE_ATAN_TINY);
-    const float mn = __builtin_fminf(ax, ay);
+    // (min of three with +inf: one v_min3_f32 — a two-operand fminf is preceded by two canonicalising v_max)
+    const float mn = __builtin_fminf(__builtin_fminf(ax, ay), __builtin_inff());
     float r = __uint_as_float(NAE_RCP_MAGIC - __float_as_uint(mx));
 #pragma unroll
     for (int it = 0; it < 3; it++) {
