@@ -107,47 +107,65 @@ __global__ __launch_bounds__(kThreads, 4) void spectrum_stereo_kernel(const floa
     const FftLds L = make_fft_lds(scratch, twa, w64, lane);
     const cf* hw = reinterpret_cast<const cf*>(hann) + lane;
     const cf* tsp = t1024 + lane;
+    const cf* tspm = t1024 + 512 - lane;                       // split twiddles of the mirrors, [-64 r]
     // (the 64-bit divisions run on the vector ALU: bring the wave-uniform results back to scalar registers)
     const int s = __builtin_amdgcn_readfirstlane((int)(item / chunks_per_stream));
     const int f0 = __builtin_amdgcn_readfirstlane((int)(item % chunks_per_stream)) * chunk;
     const int f1 = f0 + chunk > (int)n_frames ? (int)n_frames : f0 + chunk;
     const float* sbase = src + (long long)s * src_ss + 4 * lane;   // frames lie fully inside [0, T) by construction
     float* obase = dst + (long long)s * dst_ss;
+    // magnitudes of one channel: [0..3] bins lane + 64 r, [4..7] their mirrors 512 - lane - 64 r, [8] bin 256 (lane 0)
     float ma[9], mb[9];
     auto store_frame = [&](int fs) {
         // buffer stores: scalar descriptor of the frame's two spectra + one lane offset (no 64-bit per-lane addresses)
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(obase + ((long long)fs * 2) * NAE_FFT_BINS, 0, -1, 0x00020000);
 #pragma unroll
-        for (int r = 0; r < 8; r++) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ma[r]), rs, 4 * lane, 256 * r, kSpecStoreAux);
-        if (lane == 0) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ma[8]), rs, 2048, 0, kSpecStoreAux);
+        for (int c = 0; c < 2; c++) {
+            const float (&m)[9] = c == 0 ? ma : mb;
+            const int co = c * NAE_FFT_BINS * 4;
 #pragma unroll
-        for (int r = 0; r < 8; r++) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mb[r]), rs, 4 * lane, NAE_FFT_BINS * 4 + 256 * r, kSpecStoreAux);
-        if (lane == 0) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mb[8]), rs, 2048, NAE_FFT_BINS * 4, kSpecStoreAux);
+            for (int r = 0; r < 4; r++) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m[r]), rs, 4 * lane, co + 256 * r, kSpecStoreAux);
+#pragma unroll
+            for (int r = 0; r < 4; r++) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m[4 + r]), rs, 1280 - 4 * lane, co + 768 - 256 * r, kSpecStoreAux);   // bin 512 - lane - 64 r
+            if (lane == 0) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m[8]), rs, 1024, co, kSpecStoreAux);
+        }
     };
     // one channel: FFT, r2c split delivering 2 X (no 1/2 factors: |2 X|^2 = 4 |X|^2 and sqrt(4 a) = 2 sqrt(a) are exact
-    // scalings, so 0.5 * sqrt(.) is the canonical magnitude bit for bit, for |X| above ~1e-18), magnitudes
+    // scalings, so 0.5 * sqrt(.) is the canonical magnitude bit for bit, for |X| above ~1e-18), magnitudes.
+    // Bins in mirror pairs: a lane computes X[k] and X[512 - k], k = lane + 64 r, r < 4, from A = Z[k] (its own register) and
+    // B = Z[512 - k] (the upper half of Z, handed over through LDS: 4 + 1 writes and 4 reads instead of 8 + 1 and 8) — the
+    // mirror's E and O are (Ex, -Ey) and (-Ox, Oy), exact negations and commuted sums of the canonical formula.
     auto channel = [&](cf (&v)[8], float (&mc)[9]) {
         fft512_pad(v, L);
 #pragma unroll
-        for (int r = 0; r < 8; r++) lds_st(L.nat + 64 * r, v[r]);
-        if (lane == 0) scratch[512] = v[0];
+        for (int r = 4; r < 8; r++) lds_st(L.nat + 64 * r, v[r]);
+        if (lane == 0) scratch[512] = v[0];                  // the mirror of bin 0 is read like any other
         wave_lds_sync();
-        const cf z0 = scratch[0];
+        cf B[4], tk[4], tm[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) B[r] = lds_ld(L.mir + 448 - 64 * r);
+#pragma unroll
+        for (int r = 0; r < 4; r++) { tk[r] = lds_ld(tsp + 64 * r); tm[r] = lds_ld(tspm - 64 * r); }
         {
-            const cf E = cf{z0.x + z0.x, z0.y - z0.y};
-            const cf O = cf{z0.x - z0.x, z0.y + z0.y};
-            const cf P = cmul_tw(O, t1024[512]);
-            const cf nyq = cf{E.x + P.y, E.y - P.x};
-            mc[8] = 0.5f * sqrt_rn(nyq.x * nyq.x + nyq.y * nyq.y);
+            // bin 256 = its own mirror: A = B = Z[256], held by lane 0 in v[4]
+            const cf z = v[4];
+            const cf E = cf{z.x + z.x, z.y - z.y};
+            const cf O = cf{z.x - z.x, z.y + z.y};
+            const cf P = cmul_tw(O, t1024[256]);
+            const cf X = cf{E.x + P.y, E.y - P.x};
+            mc[8] = 0.5f * sqrt_rn(X.x * X.x + X.y * X.y);
         }
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const cf A = v[r], B = lds_ld(L.mir + 448 - 64 * r);
-            const cf E = cf{A.x + B.x, A.y - B.y};
-            const cf O = cf{A.x - B.x, A.y + B.y};
-            const cf P = cmul_tw(O, lds_ld(tsp + 64 * r));
+        for (int r = 0; r < 4; r++) {
+            const cf A = v[r];
+            const cf E = cf{A.x + B[r].x, A.y - B[r].y};
+            const cf O = cf{A.x - B[r].x, A.y + B[r].y};
+            const cf P = cmul_tw(O, tk[r]);
             const cf X = cf{E.x + P.y, E.y - P.x};
             mc[r] = 0.5f * sqrt_rn(X.x * X.x + X.y * X.y);
+            const cf Pm = cmul_tw(cf{-O.x, O.y}, tm[r]);
+            const cf Xm = cf{E.x + Pm.y, -E.y - Pm.x};
+            mc[4 + r] = 0.5f * sqrt_rn(Xm.x * Xm.x + Xm.y * Xm.y);
         }
         wave_lds_sync();
     };
