@@ -61,8 +61,9 @@
 
 /* N2 input resampler: libswresample's defaults when only rates / formats / layouts are set (SURVEY.md Appendix B;
  * /root/reference/src/processor/audio-amix.cpp:217-232 never touches the resampler options): polyphase
- * Kaiser-windowed sinc, filter_size 32, phase_shift 10 (1024 phases, nearest phase, no interpolation between phases),
- * kaiser_beta 9, cutoff 0.97.  Restated from public knowledge of FFmpeg 7.1's resample.c — UNPINNED versus FFmpeg. */
+ * Kaiser-windowed sinc, filter_size 32, phase_shift 10 (at most 1024 phases, nearest phase, no interpolation between phases),
+ * kaiser_beta 9, cutoff 0.97, exact_rational on (a ratio out/in whose reduced numerator is <= 1024 uses exactly that many
+ * phases: 160 for 44.1 -> 48 kHz, 320 for 22.05 -> 48, 6 for 8 -> 48, 1 for 96 -> 48; others keep 1024).  Restated from public knowledge of FFmpeg 7.1's resample.c — UNPINNED versus FFmpeg. */
 #define NAE_SWR_FILTER_SIZE 32
 #define NAE_SWR_PHASE_SHIFT 10
 #define NAE_SWR_KAISER_BETA 9.0

@@ -3,7 +3,7 @@
 // include/utility/sw-resample.hpp:55-70): any supported sample format / mono|stereo / rate -> out_rate stereo f32.
 //
 // Rate conversion follows libswresample's DEFAULT resampler (the reference sets no resampler option): polyphase
-// Kaiser-windowed sinc, filter_size 32, phase_shift 10 (1024 phases, nearest phase), kaiser_beta 9, cutoff 0.97, the
+// Kaiser-windowed sinc, filter_size 32, phase_shift 10 (at most 1024 phases; exact_rational: 160 for 44.1 -> 48 kHz), nearest phase, kaiser_beta 9, cutoff 0.97, the
 // signal reflected about its first sample and behind its last one — specification in include/nae_dsp_spec.h and
 // oracle/orc_swr.c.  UNPINNED versus FFmpeg (the library is absent; x86 builds sum the taps in SIMD order); GPU output is
 // bit-identical to the oracle, the oracle within 1e-7 of the float64 golden.
@@ -48,6 +48,11 @@ int swr_plan_make(int in_rate, int out_rate, SwrPlan* p)
     p->in_rate = in_rate;
     p->out_rate = out_rate;
     p->P = 1 << NAE_SWR_PHASE_SHIFT;
+    {
+        // exact_rational (the library's default): a ratio whose reduced numerator fits the phase table uses exactly that many phases
+        const long long exact = (long long)out_rate / gcd_ll(out_rate, in_rate);
+        if (exact <= p->P) p->P = (int)exact;
+    }
     p->factor = (double)out_rate * NAE_SWR_CUTOFF / (double)in_rate;
     if (p->factor > 1.0) p->factor = 1.0;
     p->L = (int)ceil(NAE_SWR_FILTER_SIZE / p->factor);

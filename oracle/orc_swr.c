@@ -3,7 +3,8 @@
  * What it restates: the rate conversion libswresample performs for every mixer input of the reference
  * (/root/reference/src/processor/audio-amix.cpp:212-240,263-282, audio-bimix.cpp:198-240,259-294,
  * include/utility/sw-resample.hpp:55-70) with the library's DEFAULT resampler options — the reference sets none:
- * polyphase Kaiser-windowed sinc, filter_size 32, phase_shift 10, kaiser_beta 9, cutoff 0.97, nearest phase.
+ * polyphase Kaiser-windowed sinc, filter_size 32, phase_shift 10, kaiser_beta 9, cutoff 0.97, exact_rational on,
+ * nearest phase.
  * libswresample (FFmpeg 7.1, xmake.lua:12) is a third-party dependency that is neither under /root/reference nor
  * installed here; the algorithm below follows the published structure of its resample.c / resample_template.c
  * (build_filter, swri_resample's index / frac stepping, the reflected head and tail of invert_initial_buffer and
@@ -12,7 +13,8 @@
  * the same specification, tests/golden/swr_numpy.py).
  *
  * Specification (one channel; channels are independent):
- *   factor = min(out_rate * 0.97 / in_rate, 1);  L = max(ceil(32 / factor), 1);  P = 1024
+ *   factor = min(out_rate * 0.97 / in_rate, 1);  L = max(ceil(32 / factor), 1);
+ *   P = out_rate / gcd(out_rate, in_rate) if that is <= 1024 (the library's exact_rational option, on by default), else 1024
  *   bank[ph][i] = f32( y / sum_i y ),  y = sinc(x) * I0(9 sqrt(max(1 - w^2, 0))),
  *                 x = pi ((i - (L-1)/2) - ph/P) factor,  w = 2 x / (factor L pi)           (double arithmetic)
  *   out_rate / (in_rate P) reduced by their gcd gives src_incr / dst_incr; position of output n in 1/P samples:
@@ -48,6 +50,13 @@ int orc_swr_plan_make(int in_rate, int out_rate, orc_swr_plan* p)
     p->in_rate = in_rate;
     p->out_rate = out_rate;
     p->phase_count = 1 << NAE_SWR_PHASE_SHIFT;
+    {
+        /* exact_rational (on by default): when out_rate / in_rate in lowest terms has a numerator <= 2^phase_shift, that
+         * numerator is the phase count — every output then falls exactly on a phase (44.1 -> 48 kHz: 160 phases, 147 / 160 of a
+         * sample per output; 96 -> 48 kHz: one phase).  Other ratios keep 2^phase_shift phases and the nearest-phase rule. */
+        const long long exact = (long long)out_rate / gcd_ll(out_rate, in_rate);
+        if (exact <= p->phase_count) p->phase_count = (int)exact;
+    }
     p->factor = (double)out_rate * NAE_SWR_CUTOFF / (double)in_rate;
     if (p->factor > 1.0) p->factor = 1.0;
     p->filter_length = (int)ceil(NAE_SWR_FILTER_SIZE / p->factor);

@@ -13,10 +13,19 @@ from math import ceil
 
 import numpy as np
 
-P, FILTER_SIZE, BETA, CUTOFF = 1024, 32, 9.0, 0.97
+from math import gcd
+
+P_MAX, FILTER_SIZE, BETA, CUTOFF = 1024, 32, 9.0, 0.97
+
+
+def phase_count(in_rate, out_rate):
+    """exact_rational (libswresample's default): the reduced numerator of out/in when it fits the table, else 1024"""
+    exact = out_rate // gcd(out_rate, in_rate)
+    return exact if exact <= P_MAX else P_MAX
 
 
 def bank64(in_rate, out_rate):
+    P = phase_count(in_rate, out_rate)
     factor = min(out_rate * CUTOFF / in_rate, 1.0)
     L = max(int(ceil(FILTER_SIZE / factor)), 1)
     center = (L - 1) // 2
@@ -33,6 +42,7 @@ def resample64(x, in_rate, out_rate):
     x = np.asarray(x, np.float64)
     N = x.size
     bank, L, center = bank64(in_rate, out_rate)
+    P = phase_count(in_rate, out_rate)
     step = Fraction(in_rate * P, out_rate)                  # input position advance per output, in 1/P samples
     R = (min(N, L) + 1) // 2
     assert N > L

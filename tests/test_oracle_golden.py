@@ -249,9 +249,13 @@ def test_n2_swr_oracle_matches_float64_golden(golden, in_rate):
 
 def test_n2_swr_plan_and_edges():
     rc, pl = orc.swr_plan(44100, 48000)
-    assert rc == 0 and (pl.filter_length, pl.phase_count, pl.src_incr, pl.dst_incr_div, pl.dst_incr_mod) == (32, 1024, 5, 940, 4)
-    rc, pl = orc.swr_plan(96000, 48000)                     # down-conversion: the filter stretches by 1 / (0.5 * 0.97)
-    assert rc == 0 and pl.filter_length == 66
+    # exact_rational (libswresample's default): 48000 / 44100 = 160 / 147 -> 160 phases, every output advances 147 phase steps
+    assert rc == 0 and (pl.filter_length, pl.phase_count, pl.src_incr, pl.dst_incr_div, pl.dst_incr_mod) == (32, 160, 1, 147, 0)
+    rc, pl = orc.swr_plan(96000, 48000)                     # down-conversion: the filter stretches by 1 / (0.5 * 0.97); 1 / 2 -> one phase
+    assert rc == 0 and pl.filter_length == 66 and pl.phase_count == 1
+    assert [orc.swr_plan(r, 48000)[1].phase_count for r in (22050, 8000, 32000, 11025)] == [320, 6, 3, 640]
+    rc, pl = orc.swr_plan(44101, 48000)                     # a ratio that does not reduce keeps 2^phase_shift phases (nearest phase)
+    assert rc == 0 and pl.phase_count == 1024
     assert orc.swr_plan(48000, 1000)[0] == -2                # 48x down: beyond NAE_SWR_MAX_TAPS
     assert orc.swr_resample(np.zeros(0, np.float32), 44100, 48000).size == 0
     # unit DC gain of every phase; a constant stays that constant away from the ends and, thanks to the reflection, at them
