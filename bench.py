@@ -28,7 +28,7 @@ SEMITONES = 3.0
 BINS = 513
 # issue interval of an add/sub/mul/fma mix, cycles per wave-instruction per SIMD, by waves resident per SIMD (s_memtime,
 # tools/ubench/valu_issue.hip -> profiles/r02_valu_issue.md, row "add/sub/mul/fma mix of a radix-8 butterfly")
-VALU_MIX_CYCLES_PER_INSTR = {1: 5.44, 2: 2.72, 3: 1.82, 4: 1.94, 6: 1.65, 8: 1.26}
+VALU_MIX_CYCLES_PER_INSTR = {1: 5.44, 2: 2.72, 3: 1.82, 4: 1.94, 5: 1.8, 6: 1.65, 8: 1.26}
 
 
 def parse():
@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--total-streams", type=int, default=1024, help="streams of the whole job, sharded over the GPUs (C5: 1024; strong scaling)")
     ap.add_argument("--streams", type=int, default=None, help="weak scaling instead: this many streams on EVERY GPU")
-    ap.add_argument("--sustain-seconds", type=float, default=0.0, help="also report ms per step over a back-to-back run of at least this long")
+    ap.add_argument("--sustain-seconds", type=float, default=3.0, help="also report ms per step over a back-to-back run of at least this long (0: skip)")
     ap.add_argument("--seconds", type=float, default=10.0, help="length of every stream at 48 kHz (C5: 10 s)")
     ap.add_argument("--cpu-streams", type=int, default=128, help="streams the CPU-oracle baseline is timed on")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -207,8 +207,8 @@ def main():
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "traffic_source": tdata.get("_source") if traffic is not None else None,
                     "avg_launch_ms": round(avg_s * 1e3, 4), "alg_bytes_per_launch": alg_bytes.get(dom, 0.0),
-                    "note": "K7 is bound by vector-instruction issue and LDS traffic (two 512-point FFTs, atan2, sin/cos per bin), not by "
-                            "HBM; see the valu block, DESIGN.md §4 and profiles/"}
+                    "note": "K7 is bound by vector-instruction issue PLUS LDS time (two 512-point FFTs, atan2, sin/cos per bin), not by HBM: on "
+                            "gfx950 the two add up instead of overlapping (valu.issue_plus_lds; DESIGN.md §4 and profiles/)"}
         if scale and "valu_instr_per_launch" in td:
             # vector-instruction issue: dynamic wave-instructions of the launch (SQ_INSTS_VALU) against the issue interval measured
             # with s_memtime for an add/sub/mul/fma mix at this kernel's waves per SIMD (profiles/r02_valu_issue.md), at the clock
@@ -221,6 +221,12 @@ def main():
                                 "frac": round(peak_cpi / ach_cpi, 3),
                                 "lds": {"idx_active_cycles_per_cu": td.get("lds_idx_active_per_cu", None) and td["lds_idx_active_per_cu"] * scale,
                                         "kernel_cycles": avg_s * clock_ghz * 1e9}}
+            if td.get("lds_idx_active_per_cu"):
+                # what the kernel's time is made of: vector issue at the measured interval + LDS-array cycles, per CU
+                v_cyc = instr / 1024.0 * peak_cpi
+                l_cyc = td["lds_idx_active_per_cu"] * scale
+                roofline["valu"]["issue_plus_lds"] = {"valu_cycles_per_cu": v_cyc, "lds_cycles_per_cu": l_cyc, "kernel_cycles": avg_s * clock_ghz * 1e9,
+                                                      "frac": round((v_cyc + l_cyc) / (avg_s * clock_ghz * 1e9), 3)}
     chain_gbs = 64.03 * (n_streams * S * a.steps / elapsed) / 1e9   # 24 + 16 + 24.03 B per sample-frame, rank 0's GPU
 
     out = {

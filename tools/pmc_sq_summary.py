@@ -23,7 +23,37 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # kernel symbol -> the launch label bench.py reports it under
 LABEL = {"pv_pipe_kernel": "pv_synth_kernel", "spectrum_stereo_kernel": "spectrum_kernel"}
-WAVES_PER_SIMD = {"pv_pipe_kernel": 6, "spectrum_stereo_kernel": 4, "mix_resample_tile_kernel": 5}
+WAVES_PER_SIMD = {"pv_pipe_kernel": 8, "spectrum_stereo_kernel": 4, "mix_resample_tile_kernel": 5}
+
+
+def compiler_resources():
+    """VGPRs / SGPRs / spills / occupancy per kernel as the compiler reports them (-Rpass-analysis=kernel-resource-usage): the
+    VGPR_Count field of the rocprofv3 CSV is in allocation granules (half the registers of a wave64 kernel) and its
+    LDS_Block_Size misses dynamic LDS, so neither is quoted.  The widest instantiation of a template is listed."""
+    import subprocess
+    res = {}
+    src_dir = os.path.join(ROOT, "nodey-audio-editor_amd", "csrc")
+    for tu in ("kernels_stft.hip", "kernels_pvpipe.hip"):
+        r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
+                            "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(src_dir, tu), "-o", "/dev/null"], capture_output=True, text=True)
+        cur = None
+        for line in r.stderr.splitlines():
+            m = re.search(r"Function Name: (\S+)", line)
+            if m:
+                name = re.sub(r"^_ZN3nae\d+", "", m.group(1))
+                name = re.match(r"[a-z0-9_]+", name).group(0)
+                cur = {"name": name}
+                continue
+            for key, pat in (("vgpr", r" VGPRs: (\d+)"), ("sgpr", r"TotalSGPRs: (\d+)"), ("spill", r"VGPRs Spill: (\d+)"), ("occ", r"Occupancy \[waves/SIMD\]: (\d+)")):
+                m = re.search(pat, line)
+                if m and cur is not None:
+                    cur[key] = int(m.group(1))
+            if cur is not None and "occ" in cur and "spill" in cur and "vgpr" in cur:
+                old = res.get(cur["name"])
+                if old is None or cur["occ"] > old["occ"]:        # the instantiation the headline batch runs (8 waves per SIMD for the pipeline)
+                    res[cur["name"]] = cur
+                cur = None
+    return res
 
 
 def norm(name):
@@ -64,12 +94,14 @@ def main():
     for c in sorted({c for k in keep for c in med[k]}):
         out.append(f"| {c} | " + " | ".join(f"{med[k].get(c, float('nan')):.4g}" for k in keep) + " |")
     out += ["", "Derived (per kernel; avg ms from the --kernel-trace --stats pass):", "",
-            "| kernel | avg ms | VGPR | waves | wait_any / wave_cycles | wait_inst_any / wave_cycles | active_valu / wave_cycles | VALU instr | trans share | int share | LDS instr | "
+            "| kernel | avg ms | VGPRs (compiler) / waves per SIMD | waves | wait_any / wave_cycles | wait_inst_any / wave_cycles | active_valu / wave_cycles | VALU instr | trans share | int share | LDS instr | "
             "LDS idx-active cycles per CU | bank-conflict share |", "|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
+    cres = compiler_resources()
+    vg = lambda k: (f"{cres[k]['vgpr']} / {cres[k]['occ']}" + (f" ({cres[k]['spill']} spilled)" if cres[k].get("spill") else "")) if k in cres else "?"
     for k in keep:
         g = lambda c: med[k].get(c, float("nan"))
         wc = g("SQ_WAVE_CYCLES")
-        out.append(f"| {k} | {dur.get(k, float('nan')):.3f} | {meta[k]['vgpr']} | {g('SQ_WAVES'):.4g} | {g('SQ_WAIT_ANY') / wc:.3f} | {g('SQ_WAIT_INST_ANY') / wc:.3f} | "
+        out.append(f"| {k} | {dur.get(k, float('nan')):.3f} | {vg(k)} | {g('SQ_WAVES'):.4g} | {g('SQ_WAIT_ANY') / wc:.3f} | {g('SQ_WAIT_INST_ANY') / wc:.3f} | "
                    f"{g('SQ_ACTIVE_INST_VALU') / wc:.3f} | {g('SQ_INSTS_VALU'):.4g} | {g('SQ_INSTS_VALU_TRANS_F32') / g('SQ_INSTS_VALU'):.3f} | "
                    f"{(g('SQ_INSTS_VALU_INT32') + g('SQ_INSTS_VALU_INT64')) / g('SQ_INSTS_VALU'):.3f} | {g('SQ_INSTS_LDS'):.4g} | {g('SQ_LDS_IDX_ACTIVE') / 256:.4g} | "
                    f"{g('SQ_LDS_BANK_CONFLICT') / g('SQ_LDS_IDX_ACTIVE'):.3f} |")
@@ -77,8 +109,8 @@ def main():
 
     traffic = {"_source": f"profiles/{tag}_pmc.md, profiles/{tag}_sq_stalls.md (rocprofv3 --pmc passes of this build, tools/pmc_sq.sh)"}
     lines = [f"# {tag}: HBM traffic per launch from rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes)", "", f"sample-frames per launch: {sf}", "",
-             "| kernel | avg ms (--kernel-trace --stats) | FETCH_SIZE KiB (raw) | read bytes (x2 gfx950 corr.) | WRITE_SIZE KiB | HBM bytes/launch | B per sample-frame | VGPR | LDS B/WG |",
-             "|---|---|---|---|---|---|---|---|---|"]
+             "| kernel | avg ms (--kernel-trace --stats) | FETCH_SIZE KiB (raw) | read bytes (x2 gfx950 corr.) | WRITE_SIZE KiB | HBM bytes/launch | B per sample-frame | VGPRs (compiler) / waves per SIMD |",
+             "|---|---|---|---|---|---|---|---|"]
     for k in keep:
         if "FETCH_SIZE" not in med[k]:
             continue
@@ -87,7 +119,7 @@ def main():
                                     "valu_instr_per_launch": med[k].get("SQ_INSTS_VALU"), "lds_idx_active_per_cu": med[k].get("SQ_LDS_IDX_ACTIVE", 0) / 256,
                                     "waves_per_simd": WAVES_PER_SIMD.get(k, 4)}
         lines.append(f"| {k} | {dur.get(k, float('nan')):.3f} | {med[k]['FETCH_SIZE']:.0f} | {rd:.4g} | {med[k].get('WRITE_SIZE', 0):.0f} | {rd + wr:.4g} | {(rd + wr) / sf:.2f} | "
-                     f"{meta[k]['vgpr']} | {meta[k]['lds']} |")
+                     f"{vg(k)} |")
     open(os.path.join(prof, f"{tag}_pmc.md"), "w").write("\n".join(lines) + "\n")
     json.dump(traffic, open(os.path.join(prof, "traffic.json"), "w"), indent=1)
     print("\n".join(out[-len(keep) - 3:]))
