@@ -85,8 +85,9 @@ def test_c5_batch_equals_streams_run_alone_and_the_oracle(ctx, nae):
 
 
 def test_c5_eighth_of_the_job_128_streams(ctx, nae):
-    """What one rank of the 8-GPU job owns (BASELINE.json configs[4]: 1024 streams over 8 GPUs): 128 streams are fewer
-    stream-channels than the chip has wave slots, so the vocoder runs in time tiles (pass 1 + scan + synthesis with carried
+    """What one rank of the 8-GPU job owns (BASELINE.json configs[4]: 1024 streams over 8 GPUs): 128 streams are 256
+    stream-channels = one workgroup per CU, so the vocoder runs frame-interleaved (four consecutive frames of a stream-channel per
+    step, no time tiles, nothing analysed twice), while a lone stream is cut into time tiles on top (pass 1 + scan + carried
     phases).  Every stream equals its lone run bit for bit; three streams are compared with the oracle."""
     n_streams, S, p, first = 128, 480000, 2 ** (3 / 12), 896            # rank 7 of 8 owns streams 896..1023
     d_a, d_b = ctx.empty(n_streams * S * 2), ctx.empty(S * 2)

@@ -3,6 +3,8 @@
 Bars: K8 is bit-exact against the oracle (the phase path is specified to the operation) and <= 1e-4 relative RMS
 against the float64 DFT golden; K7's integer synthesis phases are bit-exact and its samples are within the
 1e-4 RMS tolerance BASELINE.json states for float paths."""
+import os
+
 import numpy as np
 import pytest
 
@@ -453,3 +455,29 @@ def test_k7_k8_odd_layouts_equal_clean_layouts(ctx, nae):
             ref = gpu_spectrum(ctx, nae, x, ch, n_streams)
             assert np.array_equal(d_o.download().reshape(ref.shape).view(np.uint32), ref.view(np.uint32))
             d_src.free(); d_dst.free(); d_o.free()
+
+
+@pytest.mark.parametrize("ch,n_streams,L,rate,pitch", [(2, 3, 30000, 1.0, 2 ** (3 / 12)), (1, 5, 21001, 1.0, 2 ** (-4 / 12)), (2, 2, 9000, 1.5, 1 / 1.5)])
+def test_k7_pipeline_modes_agree_bit_for_bit(nae, ch, n_streams, L, rate, pitch):
+    """The vocoder pipeline runs a stream-channel through its four roles one frame per step (large batches) or 2 / 4 consecutive
+    frames per step (frame-interleaved: small batches), with or without time tiles (pass 1 + scan).  All shapes deliver the same
+    samples bit for bit — same integer phases, same overlap-add order — and match the oracle within the tolerance.  The shapes are
+    forced through the tuning knobs NAE_PV_FPS / NAE_PV_TILE, read when a context is created."""
+    x = (0.5 * orc.fill_uniform(n_streams * L * ch, 77)).astype(np.float32)
+    outs = {}
+    try:
+        for fps in ("1", "2", "4"):
+            for tile in ("0", "64"):
+                os.environ["NAE_PV_FPS"], os.environ["NAE_PV_TILE"] = fps, tile
+                with nae.Context(0) as c:
+                    outs[(fps, tile)] = gpu_stretch(c, nae, x, ch, rate, pitch, n_streams=n_streams)[0]
+    finally:
+        os.environ.pop("NAE_PV_FPS", None)
+        os.environ.pop("NAE_PV_TILE", None)
+    first = outs[("1", "0")]
+    for key, o in outs.items():
+        assert np.array_equal(o.view(np.uint32), first.view(np.uint32)), key
+    per = first.reshape(n_streams, -1)
+    for s in (0, n_streams - 1):
+        ref = orc.stretch(x.reshape(n_streams, -1)[s], ch, rate, pitch)
+        assert rel_rms(per[s], ref) <= TOL

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Time every BASELINE.json config on one MI355X and print a markdown table (profiles/r01_configs.md is its output).
+"""Time every BASELINE.json config on one MI355X and print a markdown table (profiles/r0N_configs.md is its output).
 Lives under tests/ because it checks parity against, and times, the CPU oracle (only tests/, smoke() and bench.py may).
 bench.py remains the contract benchmark (C5); this tool covers C1-C4 and the per-node kernels."""
 import os
