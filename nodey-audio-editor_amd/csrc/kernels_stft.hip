@@ -357,6 +357,28 @@ constexpr int kRsRow = 20;                       // LDS row stride of the coeffi
                                                  // stride maps every row to one of 4 bank slots (4-way conflicts on b128)
 constexpr int kRsMaxSpan = 4096 + 32;            // staged source samples per channel (rho <= 4)
 
+// coefficient table -> LDS (rows rotated by rs_slot): 16-byte loads, ALL of a thread's loads requested before the first LDS write.
+// (The table is 8 KB per workgroup out of L2; one dword per thread and trip with a wait in every trip — what the first version
+// did — put eight serial L2 round trips in front of every workgroup's staging loads.)
+__device__ __forceinline__ void rs_fill_table(float* stab, const float* __restrict__ tab, int rot)
+{
+    constexpr int kQuads = (NAE_RS_PHASES + 1) * (NAE_RS_TAPS / 4);          // 516 float4
+    constexpr int kTrips = (kQuads + 255) / 256;
+    const float4* t4 = reinterpret_cast<const float4*>(tab);
+    float4 v[kTrips];
+#pragma unroll
+    for (int u = 0; u < kTrips; u++) {
+        const int i = threadIdx.x + 256 * u;
+        v[u] = i < kQuads ? t4[i] : float4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+#pragma unroll
+    for (int u = 0; u < kTrips; u++) {
+        const int i = threadIdx.x + 256 * u;
+        if (i < kQuads) *reinterpret_cast<float4*>(stab + rs_slot(i >> 2, rot) * kRsRow + 4 * (i & 3)) = v[u];
+    }
+}
+
+
 // kStereo: the two channels are staged INTERLEAVED in LDS so one ds_read_b64 per tap feeds both accumulators
 // (the tap reads, not HBM, bound this kernel: 16 per channel-output).
 // kStereo && NS > 1: one workgroup produces the same output tile for NS streams.  The 16 interpolated coefficients
@@ -418,8 +440,7 @@ __global__ __launch_bounds__(256) void resample_tile_kernel(SigViewD src, RsPara
     extern __shared__ __attribute__((aligned(16))) unsigned char rs_smem[];
     float* stab = reinterpret_cast<float*>(rs_smem);                           // (PHASES+1) x kRsRow
     float* stage = stab + (NAE_RS_PHASES + 1) * kRsRow;                        // stereo: [NS][span_alloc][2]; else [ch][span_alloc]
-    for (int i = threadIdx.x; i < (NAE_RS_PHASES + 1) * NAE_RS_TAPS; i += 256)
-        stab[rs_slot(i / NAE_RS_TAPS, p.rot) * kRsRow + (i % NAE_RS_TAPS)] = tab[i];
+    rs_fill_table(stab, tab, p.rot);
     const long long s0 = (long long)blockIdx.y * NS;
     const long long j0 = p.j_begin + (long long)blockIdx.x * kRsOut;
     long long j1 = j0 + kRsOut;
@@ -526,8 +547,6 @@ __global__ __launch_bounds__(256) void mix_resample_tile_kernel(MixFuseD f, RsPa
     extern __shared__ __attribute__((aligned(16))) unsigned char rs_smem[];
     float* stab = reinterpret_cast<float*>(rs_smem);
     float* stage = stab + (NAE_RS_PHASES + 1) * kRsRow;
-    for (int i = threadIdx.x; i < (NAE_RS_PHASES + 1) * NAE_RS_TAPS; i += 256)
-        stab[rs_slot(i / NAE_RS_TAPS, p.rot) * kRsRow + (i % NAE_RS_TAPS)] = tab[i];
     const long long s0 = (long long)blockIdx.y * NS;
     const long long j0 = (long long)blockIdx.x * kRsOut;
     long long j1 = j0 + kRsOut;
@@ -548,8 +567,7 @@ __global__ __launch_bounds__(256) void mix_resample_tile_kernel(MixFuseD f, RsPa
     // streams are issued before anything is stored — the staging is bound by round trips to HBM — and the mix leaves
     // as 16-byte stores per plane, like the stand-alone mix kernel's.
     const long long m_end = last ? (p.src_len > m_hi ? p.src_len : m_hi) : m_hi;
-    for (long long m = m_lo + 4 * threadIdx.x; m < m_end; m += 4 * 256) {
-        float4 xa[NS][2], xb[NS][2];
+    auto load = [&](long long m, float4 (&xa)[NS][2], float4 (&xb)[NS][2]) {
         const bool inside = m >= 0 && m + 4 <= p.src_len;
 #pragma unroll
         for (int k = 0; k < NS; k++) {
@@ -577,6 +595,8 @@ __global__ __launch_bounds__(256) void mix_resample_tile_kernel(MixFuseD f, RsPa
                 }
             }
         }
+    };
+    auto finish = [&](long long m, const float4 (&xa)[NS][2], const float4 (&xb)[NS][2]) {
         bool own[4], in[4];
 #pragma unroll
         for (int e = 0; e < 4; e++) {
@@ -612,6 +632,20 @@ __global__ __launch_bounds__(256) void mix_resample_tile_kernel(MixFuseD f, RsPa
                 }
             }
         }
+    };
+    // first trip: its HBM loads are requested, THEN the coefficient table (L2) is fetched and laid out while they travel
+    {
+        float4 xa[NS][2], xb[NS][2];
+        const long long m = m_lo + 4 * threadIdx.x;
+        const bool has = m < m_end;
+        if (has) load(m, xa, xb);
+        rs_fill_table(stab, tab, p.rot);
+        if (has) finish(m, xa, xb);
+    }
+    for (long long m = m_lo + 4 * threadIdx.x + 4 * 256; m < m_end; m += 4 * 256) {
+        float4 xa[NS][2], xb[NS][2];
+        load(m, xa, xb);
+        finish(m, xa, xb);
     }
     __syncthreads();
     rs_apply_stereo<NS>(stab, stage, span_alloc, p, j0, j1, m_lo, out, s0, n_streams);
