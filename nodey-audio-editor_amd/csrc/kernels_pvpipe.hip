@@ -56,17 +56,25 @@ static_assert(pipe_lds(2, 4) <= 160 * 1024 && pipe_lds(4, 4) <= 160 * 1024, "one
 __device__ __forceinline__ void pipe_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // Issue priority (kG = 1).  Two workgroups share a CU and the hardware arbitrates equal priorities by age, so the workgroup that
-// arrived first runs its steps faster than its neighbour on every CU (profiles/r02_pipe_stamps_per_cu.txt).  They take turns: a
-// workgroup learns whether it was the first or the second on its CU (g_cu_arrivals, counted per physical CU, never reset: only
-// the parity is used) and raises its priority on alternate steps; the role that ends a step's critical path (R3) sits one
-// level above its workgroup's (6.80 ms against 6.85 without and 7.00 with the phase role R2b up there instead, one box).
-// Measured and dropped: keeping the pair level by feedback — each workgroup publishing its step counter, whoever is behind at the
-// higher priority — levels them at the pace of the SLOWER one (7.8 against 7.3 ms); static priorities by role; two-slot
-// (eight-wave) workgroups, four per CU, each at its own pace (within 1 %).
+// arrived first runs its steps 30-40 % faster than its neighbour on every CU, finishes early and leaves the CU half empty
+// (profiles/r02_pipe_stamps_per_cu.txt, r03_pipe_stamps_1024_streams.txt).  An uneven pair is not the problem — the favoured
+// workgroup runs a step in 4800 cycles against 4140 alone on the CU while its neighbour still advances: more frames per cycle
+// than two workgroups at equal priority — the early finish is.  So the two take turns at the higher priority in TIME SLICES of
+// 2^18 shader cycles (0.13 ms, ~50 steps): both read the same clock (s_memtime, requested behind barrier B and used behind
+// the next barrier A, where the wave has waited for lgkmcnt(0) anyway), a workgroup learns whether it was the first or the second
+// on its CU from an arrival counter per physical CU (never reset: only the parity is used), and the two progress at the same
+// average pace.  The role that ends a step's critical path most often (R3) sits one level above its workgroup's.
+// Measured on one box (vocoder kernel, ms): step-parity turns 6.56, slices of 2^12 cycles 6.6, 2^15 6.38, 2^16 6.26, 2^18 6.19,
+// 2^19 6.19, 2^21 6.31, 2^23 6.75; with 2^18: no role up 6.50, R1 and R3 up 6.33, R2a / R2b up 6.69, R1 up 6.61, R3 up 6.31.
+// Measured and dropped: keeping the pair level by feedback (each workgroup publishing its step counter, whoever is behind at the
+// higher priority: both then run at the pace of the slower, 7.8 against 7.3 ms); two-slot (eight-wave) workgroups, four per CU
+// (within 1 %).
+constexpr int kPrioSliceBit = 18;
 __device__ unsigned g_cu_arrivals[8 * 4 * 16];
-__device__ __forceinline__ void pipe_prio(int t, int slot, int role)
+__device__ __forceinline__ void pipe_prio(int slot, int role, unsigned long long now)
 {
-    const int lvl = (((t + slot) & 1) ? 2 : 0) + (role == 3 ? 1 : 0);                   // wave-uniform
+    const int turn = (int)((now >> kPrioSliceBit) & 1);
+    const int lvl = (((turn + slot) & 1) ? 2 : 0) + (role == 3 ? 1 : 0);                // wave-uniform
     if (lvl == 0) __builtin_amdgcn_s_setprio(0);
     else if (lvl == 1) __builtin_amdgcn_s_setprio(1);
     else if (lvl == 2) __builtin_amdgcn_s_setprio(2);
@@ -170,6 +178,8 @@ __global__ __launch_bounds__(pipe_threads(kS), kRich ? (kS == 4 ? 4 : 2) : 8) vo
     const int steps = (n + kG - 1) / kG;
     const int T = steps + kDepth;
     /*pipe:begin*/
+    unsigned long long now = 0;                              // shader clock, read behind barrier B, used behind the next barrier A
+    if (kG > 1 && role == 2) __builtin_amdgcn_s_setprio(1);   // frame-interleaved (one workgroup per CU): R2b one level up (1.10 against 1.15 ms at 128 streams)
 
     if (role == 0) {
         // ------------------------------------------------------------------------------------------ R1: analysis FFT
@@ -189,7 +199,7 @@ __global__ __launch_bounds__(pipe_threads(kS), kRich ? (kS == 4 ? 4 : 2) : 8) vo
         for (int t = 0; t < T; t++) {
             const bool cur = kG * t + j < n;
             pipe_barrier();                                   /*A*/
-            if (kG == 1) pipe_prio(t, prio_slot, role);
+            if (kG == 1) pipe_prio(prio_slot, role, now);
             if (cur) {
                 // register-only part while R2 reads Z of the previous step out of this wave's scratch.  Window and pass-A
                 // twiddles are requested together (one LDS round trip): the accesses are volatile, so the compiler keeps them
@@ -213,6 +223,7 @@ __global__ __launch_bounds__(pipe_threads(kS), kRich ? (kS == 4 ? 4 : 2) : 8) vo
                 }
             }
             pipe_barrier();                                   /*B*/
+            if (kG == 1) now = __builtin_amdgcn_s_memtime();
             if (cur) {
                 const FftLds L = make_fft_lds(S1, twa, w64, pipe_lane(lane));
                 cf none[8];
@@ -299,7 +310,7 @@ __global__ __launch_bounds__(pipe_threads(kS), kRich ? (kS == 4 ? 4 : 2) : 8) vo
             const bool act_b = kG > 1 && t >= 2 && ib < n;
             const long long fb = f_first + ib;
             pipe_barrier();                                   /*A*/  // Z of frame fa is complete
-            if (kG == 1) pipe_prio(t, prio_slot, role);
+            if (kG == 1) pipe_prio(prio_slot, role, now);
             cf va[5];
             if (act_a) {
                 const int kk = pipe_lane(k0);
@@ -357,6 +368,7 @@ __global__ __launch_bounds__(pipe_threads(kS), kRich ? (kS == 4 ? 4 : 2) : 8) vo
                 if (dc) pi[512] = inc[4];
             }
             pipe_barrier();                                   /*B*/  // R1 may overwrite its scratch
+            if (kG == 1) now = __builtin_amdgcn_s_memtime();
             uint32_t qa[5] = {0, 0, 0, 0, 0};
             if (act_a) {
 #pragma unroll
@@ -473,7 +485,7 @@ __global__ __launch_bounds__(pipe_threads(kS), kRich ? (kS == 4 ? 4 : 2) : 8) vo
             const long long fz = f_first + iz;
             const bool active = iz >= 0 && iz < n && fz >= b0;
             pipe_barrier();                                   /*A*/  // the FFT input of frame fz is complete
-            if (kG == 1) pipe_prio(t, prio_slot, role);
+            if (kG == 1) pipe_prio(prio_slot, role, now);
             cf zs[8];
             if (active) {
                 // FFT input and pass-A twiddles in one round trip; pass A is register-only, so it runs on this side of barrier B
@@ -514,6 +526,7 @@ __global__ __launch_bounds__(pipe_threads(kS), kRich ? (kS == 4 ? 4 : 2) : 8) vo
                 }
             }
             pipe_barrier();                                   /*B*/  // R2 may overwrite the FFT input
+            if (kG == 1) now = __builtin_amdgcn_s_memtime();
             had = active;
             if (active) {
                 const int lb = pipe_lane(lane);
