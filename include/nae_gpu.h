@@ -244,7 +244,7 @@ int nae_wsola_destroy(nae_wsola* h);
  * 259-294; utility/sw-resample.hpp:55-70): any supported format / mono|stereo / rate -> `out_rate` stereo f32.
  * Identity inputs (same rate, stereo float) are a bit copy — the only case the reference pins.  Everything else restates
  * libswresample's defaults and is UNPINNED versus FFmpeg itself: sample scaling as K6, mono -> stereo as L = R = m/sqrt(2)
- * (swr's default float rematrix), rate change by swr's default polyphase resampler (filter_size 32, 1024 phases, nearest
+ * (swr's default float rematrix), rate change by swr's default polyphase resampler (filter_size 32, at most 1024 phases — exact_rational: 160 for 44.1 -> 48 kHz —, nearest
  * phase, Kaiser beta 9, cutoff 0.97, reflected ends; include/nae_dsp_spec.h, oracle/orc_swr.c).  Ratios beyond ~15x down
  * are refused with NAE_ERR_UNSUPPORTED.
  * convert() follows swr_convert(ctx, out, out_count, in, in_count): it consumes all n_in input frames, hands out at
