@@ -275,6 +275,12 @@ __global__ __launch_bounds__(pipe_threads(kS), kRich ? (kS == 4 ? 4 : 2) : 8) vo
             inc[3] = pipe_inc(qa[3], qv[3], (unsigned)(448 - kk), d, R);
             inc[4] = (h == 0) ? pipe_inc(qa[4], qv[4], 512u, d, R) : 0u;
         };
+        // a continued stream carries the synthesis phase behind its segment's last frame on (nae_stream.hip)
+        auto carry_store = [&](const uint32_t (&q)[5]) {
+            uint32_t* co = p.carry_out + sc * kT1024Pad;
+            co[k0] = q[0]; co[km0] = q[1]; co[k0 + 64] = q[2]; co[448 - k0] = q[3];
+            if (dc) co[512] = q[4];
+        };
         // rotation by the phase difference and the in-lane c2r pre-twiddle: R3's FFT input Zin[k], Zin[512 - k]
         // (conjugated, inverse = conj(FFT(conj Z)) / 512; 2E, 2D: see kGain)
         auto synth_items = [&](const cf (&x)[5], const uint32_t (&qsv)[5], const uint32_t (&qav)[5]) {
@@ -393,6 +399,7 @@ __global__ __launch_bounds__(pipe_threads(kS), kRich ? (kS == 4 ? 4 : 2) : 8) vo
                     }
 #pragma unroll
                     for (int q = 0; q < 5; q++) qp[q] = qa[q];
+                    if (fa == p.carry_frame) carry_store(qs);
                     if (fa >= b0) synth_items(va, qs, qa);
                 }
             } else {
@@ -422,6 +429,7 @@ __global__ __launch_bounds__(pipe_threads(kS), kRich ? (kS == 4 ? 4 : 2) : 8) vo
                     }
 #pragma unroll
                     for (int q = 0; q < 5; q++) qs[q] = base[q];
+                    if (fb == p.carry_frame) carry_store(mine);
                     if (fb >= b0) synth_items(hx, mine, hqa);
                 }
                 if (act_a) {

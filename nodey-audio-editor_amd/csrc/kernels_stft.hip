@@ -767,6 +767,8 @@ static PvParams make_pv_params(const nae_stretch_plan& pl, size_t in_len, int ch
     p.skip_from = p.n_tiles;
     p.phase_step = 1;
     p.phase_tiles = p.n_tiles;
+    p.carry_out = nullptr;
+    p.carry_frame = -1;
     return p;
 }
 
@@ -788,7 +790,7 @@ int nae_launch_pv_phase(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig*
     PvParams p = make_pv_params(*pl, in_len, ch, tile, seg);
     const long long n_sc = (long long)n_streams * ch;
     if (n_sc * p.n_tiles == 0) return NAE_OK;
-    const bool need_last = seg && seg->carry_out;
+    const bool need_last = seg && seg->carry_out && !seg->carry_by_synth;
     const int step = synth_tile / tile;
     const int n_synth = (p.n_tiles + step - 1) / step;
     const int n_needed = need_last ? p.n_tiles : (n_synth - 1) * step;      // sums of tiles [0, n_needed) are used
@@ -839,6 +841,11 @@ int nae_launch_pv_synth(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig*
     const long long cnt = p.f_stop - p.f_origin;
     p.phase_step = tile / phase_tile;
     p.phase_tiles = (int)((cnt + phase_tile - 1) / phase_tile);
+    if (seg && seg->carry_by_synth && seg->carry_out) {
+        if (p.n_tiles != 1) return nae_fail(ctx, NAE_ERR_INVALID, "carry_by_synth needs a single synthesis tile");
+        p.carry_out = seg->carry_out;
+        p.carry_frame = p.f_stop - 1;
+    }
     return nae_launch_pv_pipe(ctx, p, to_view(src), (long long)n_streams * ch, phase_ws, to_out(out), src->frame_stride == 1, frames_per_step);
 }
 

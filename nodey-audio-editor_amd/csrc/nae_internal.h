@@ -72,6 +72,7 @@ struct nae_pv_segment {
     long long mid_limit;          // stretched samples >= mid_limit are not stored
     const uint32_t* carry_in;     // [n_streams*ch][520] phase behind frame f_origin-1 (null: zero)
     uint32_t* carry_out;          // receives the phase behind frame f_origin+f_count-1 (null: not wanted)
+    bool carry_by_synth = false;  // the segment is synthesised as ONE tile and pass 3 itself writes carry_out (no pass 1)
 };
 size_t nae_pv_phase_workspace_bytes(size_t n_frames, int ch, size_t n_streams, int tile);
 int nae_launch_pv_phase(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig* src, size_t in_len, int ch,

@@ -121,15 +121,20 @@ int stretch_process(nae_stretch* h)
             out_limit = (long long)1 << 60;
         }
         if (B_r > h->blocks_done) {
-            const int tile = ctx->pv_tile > 0 ? ctx->pv_tile : 64;
             const size_t count = B_r - h->blocks_done;
+            // a short segment (what a node's batch of waiting frames gives) is ONE tile run frame-interleaved — four consecutive
+            // frames per step — and the pipeline itself hands the phase on: one launch instead of pass 1 + scan + pass 3.
+            // Long segments (a whole file in one put) are cut into 64-frame tiles that run side by side.
+            const bool one_tile = ctx->pv_tile <= 0 && count <= 256;
+            const int tile = one_tile ? (int)count : (ctx->pv_tile > 0 ? ctx->pv_tile : 64);
+            const int fps = one_tile ? 4 : 1;
             int rc = nae_ws_reserve(ctx, &ctx->ws_phase, &ctx->ws_phase_bytes, nae_pv_phase_workspace_bytes(count, ch, 1, tile));
             if (rc) return rc;
             for (int i = 0; i < 2; i++)
                 if (!h->carry[i] && hipMalloc((void**)&h->carry[i], (size_t)ch * kPhasePad * sizeof(uint32_t)) != hipSuccess)
                     return nae_fail(ctx, NAE_ERR_NOMEM, "hipMalloc(carry)");
             nae_pv_segment seg{(long long)h->blocks_done, (long long)count, (long long)F_r, out_limit,
-                               h->blocks_done ? h->carry[h->carry_cur] : nullptr, h->carry[h->carry_cur ^ 1]};
+                               h->blocks_done ? h->carry[h->carry_cur] : nullptr, h->carry[h->carry_cur ^ 1], one_tile};
             const size_t produced_total = h->flushed ? fin.out_len : B_r * NAE_HOP;
             rc = fifo_reserve_interleaved(ctx, h->out, h->out_total, produced_total, ch);
             if (rc) return rc;
@@ -137,7 +142,7 @@ int stretch_process(nae_stretch* h)
             nae_sig dst{h->out.cur.p - (ptrdiff_t)h->out.base * ch, 0, 1, (size_t)ch};
             rc = nae_launch_pv_phase(ctx, &pl, &src, h->mid_total, ch, 1, tile, tile, static_cast<uint32_t*>(ctx->ws_phase), &seg);
             if (rc) return rc;
-            rc = nae_launch_pv_synth(ctx, &pl, &src, h->mid_total, ch, 1, tile, tile, static_cast<const uint32_t*>(ctx->ws_phase), &dst, &seg, 1);
+            rc = nae_launch_pv_synth(ctx, &pl, &src, h->mid_total, ch, 1, tile, tile, static_cast<const uint32_t*>(ctx->ws_phase), &dst, &seg, fps);
             if (rc) return rc;
             h->carry_cur ^= 1;
             h->blocks_done = B_r;
@@ -163,15 +168,20 @@ int stretch_process(nae_stretch* h)
             mid_limit = (long long)1 << 60;
         }
         if (B_r > h->blocks_done) {
-            const int tile = ctx->pv_tile > 0 ? ctx->pv_tile : 64;
             const size_t count = B_r - h->blocks_done;
+            // a short segment (what a node's batch of waiting frames gives) is ONE tile run frame-interleaved — four consecutive
+            // frames per step — and the pipeline itself hands the phase on: one launch instead of pass 1 + scan + pass 3.
+            // Long segments (a whole file in one put) are cut into 64-frame tiles that run side by side.
+            const bool one_tile = ctx->pv_tile <= 0 && count <= 256;
+            const int tile = one_tile ? (int)count : (ctx->pv_tile > 0 ? ctx->pv_tile : 64);
+            const int fps = one_tile ? 4 : 1;
             int rc = nae_ws_reserve(ctx, &ctx->ws_phase, &ctx->ws_phase_bytes, nae_pv_phase_workspace_bytes(count, ch, 1, tile));
             if (rc) return rc;
             for (int i = 0; i < 2; i++)
                 if (!h->carry[i] && hipMalloc((void**)&h->carry[i], (size_t)ch * kPhasePad * sizeof(uint32_t)) != hipSuccess)
                     return nae_fail(ctx, NAE_ERR_NOMEM, "hipMalloc(carry)");
             nae_pv_segment seg{(long long)h->blocks_done, (long long)count, (long long)F_r, mid_limit,
-                               h->blocks_done ? h->carry[h->carry_cur] : nullptr, h->carry[h->carry_cur ^ 1]};
+                               h->blocks_done ? h->carry[h->carry_cur] : nullptr, h->carry[h->carry_cur ^ 1], one_tile};
             nae_sig src{h->in.cur.p - (ptrdiff_t)h->in.base * ch, 0, 1, (size_t)ch};   // absolute indexing
             nae_sig dst;
             size_t produced_total = h->flushed ? fin.mid_len : B_r * NAE_HOP;
@@ -203,7 +213,7 @@ int stretch_process(nae_stretch* h)
             }
             rc = nae_launch_pv_phase(ctx, &pl, &src, h->in_total, ch, 1, tile, tile, static_cast<uint32_t*>(ctx->ws_phase), &seg);
             if (rc) return rc;
-            rc = nae_launch_pv_synth(ctx, &pl, &src, h->in_total, ch, 1, tile, tile, static_cast<const uint32_t*>(ctx->ws_phase), &dst, &seg, 1);
+            rc = nae_launch_pv_synth(ctx, &pl, &src, h->in_total, ch, 1, tile, tile, static_cast<const uint32_t*>(ctx->ws_phase), &dst, &seg, fps);
             if (rc) return rc;
             h->carry_cur ^= 1;
             h->blocks_done = B_r;
