@@ -82,10 +82,13 @@ __device__ __forceinline__ void pipe_prio(int slot, int role, unsigned long long
 }
 
 // the lane index as a value the optimiser cannot see through: addresses derived from it are recomputed where they are used
-// (one to four instructions each) instead of being hoisted out of the frame loop, where each would pin a VGPR of the 64
+// (one to four instructions each) instead of being hoisted out of the frame loop, where each would pin a VGPR of the 64.
+// Only where that matters: R1 and R3 of the 64-VGPR build; the phase roles have registers to spare (their hoisted addresses
+// stay below the kernel's maximum: -1.7 % kernel time), and the 128-VGPR builds hide nothing
+template <bool kHide = true>
 __device__ __forceinline__ int pipe_lane(int lane)
 {
-    asm volatile("" : "+v"(lane));
+    if (kHide) asm volatile("" : "+v"(lane));
     return lane;
 }
 
@@ -204,7 +207,7 @@ __global__ __launch_bounds__(pipe_threads(kS), kRich ? (kS == 4 ? 4 : 2) : 8) vo
                 // register-only part while R2 reads Z of the previous step out of this wave's scratch.  Window and pass-A
                 // twiddles are requested together (one LDS round trip): the accesses are volatile, so the compiler keeps them
                 // where they are written, and one read per product would cost one round trip each
-                const int la = pipe_lane(lane);
+                const int la = pipe_lane<!kRich>(lane);
                 const cf* hw = reinterpret_cast<const cf*>(hann) + la;      // window of samples 2 (lane + 64 r), +1
                 const cf* ta = twa + la;
                 if (kRich) {
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(pipe_threads(kS), kRich ? (kS == 4 ? 4 : 2) : 8) vo
             pipe_barrier();                                   /*B*/
             if (kG == 1) now = __builtin_amdgcn_s_memtime();
             if (cur) {
-                const FftLds L = make_fft_lds(S1, twa, w64, pipe_lane(lane));
+                const FftLds L = make_fft_lds(S1, twa, w64, pipe_lane<!kRich>(lane));
                 cf none[8];
                 fft512_pad_bc_g<kRich, false>(va, L, r_tb, nullptr, none);
 #pragma unroll
@@ -268,7 +271,7 @@ __global__ __launch_bounds__(pipe_threads(kS), kRich ? (kS == 4 ? 4 : 2) : 8) vo
         for (int q = 0; q < 5; q++) hx[q] = cf{0.0f, 0.0f};
         // phase increment of all items of this lane (exact integers)
         auto inc_items = [&](const uint32_t (&qa)[5], const uint32_t (&qv)[5], unsigned d, unsigned R, uint32_t (&inc)[5]) {
-            const int kk = pipe_lane(k0), km = pipe_lane(km0);
+            const int kk = k0, km = km0;
             inc[0] = pipe_inc(qa[0], qv[0], (unsigned)kk, d, R);
             inc[1] = pipe_inc(qa[1], qv[1], (unsigned)km, d, R);
             inc[2] = pipe_inc(qa[2], qv[2], (unsigned)(kk + 64), d, R);
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(pipe_threads(kS), kRich ? (kS == 4 ? 4 : 2) : 8) vo
         // rotation by the phase difference and the in-lane c2r pre-twiddle: R3's FFT input Zin[k], Zin[512 - k]
         // (conjugated, inverse = conj(FFT(conj Z)) / 512; 2E, 2D: see kGain)
         auto synth_items = [&](const cf (&x)[5], const uint32_t (&qsv)[5], const uint32_t (&qav)[5]) {
-            const int kk = pipe_lane(k0), km = pipe_lane(km0);
+            const int kk = k0, km = km0;
             cf* Yk = Y + kk;
 #pragma unroll
             for (int i = 0; i < 2; i++) {
@@ -319,7 +322,7 @@ __global__ __launch_bounds__(pipe_threads(kS), kRich ? (kS == 4 ? 4 : 2) : 8) vo
             if (kG == 1) pipe_prio(prio_slot, role, now);
             cf va[5];
             if (act_a) {
-                const int kk = pipe_lane(k0);
+                const int kk = k0;
                 const cf* Zk = S1 + kk;
                 const cf* Zm = S1 + 512 - kk;
                 cf A[2], B[2];
@@ -354,7 +357,7 @@ __global__ __launch_bounds__(pipe_threads(kS), kRich ? (kS == 4 ? 4 : 2) : 8) vo
                 // increment of the held frame fb: its predecessor's analysis phases were left in LDS one step ago (slot j-1), or
                 // two steps ago by the last slot (j = 0)
                 uint32_t inc[5] = {0, 0, 0, 0, 0};
-                const int kk = pipe_lane(k0), km = pipe_lane(km0);
+                const int kk = k0, km = km0;
                 if (act_b && fb >= b0) {
                     if (fb == 0) {
 #pragma unroll
@@ -404,14 +407,14 @@ __global__ __launch_bounds__(pipe_threads(kS), kRich ? (kS == 4 ? 4 : 2) : 8) vo
                 }
             } else {
                 if (act_a) {
-                    const int kk = pipe_lane(k0), km = pipe_lane(km0);
+                    const int kk = k0, km = km0;
                     uint32_t* pq = x_qa(slot, t & 1);
                     pq[kk] = qa[0]; pq[km] = qa[1]; pq[kk + 64] = qa[2]; pq[448 - kk] = qa[3];
                     if (dc) pq[512] = qa[4];
                 }
                 if (act_b) {
                     // running phase: the increments of the unit's slots up to this one; all of them move the base on
-                    const int kk = pipe_lane(k0), km = pipe_lane(km0);
+                    const int kk = k0, km = km0;
                     uint32_t mine[5], base[5];
 #pragma unroll
                     for (int q = 0; q < 5; q++) { mine[q] = qs[q]; base[q] = qs[q]; }
@@ -467,7 +470,7 @@ __global__ __launch_bounds__(pipe_threads(kS), kRich ? (kS == 4 ? 4 : 2) : 8) vo
                 float* pb = optr + be * NAE_HOP * out.fs;
                 const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(pb, 0, -1, 0x00020000);
                 auto st = [&](unsigned byte_off, float v) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, (int)byte_off, 0, 0); };
-                const int ls = pipe_lane(lane);
+                const int ls = pipe_lane<!kRich>(lane);
                 const unsigned fs4 = 4u * (unsigned)out.fs;                 // bytes between consecutive samples
                 const unsigned oa = 2u * (unsigned)ls * fs4;                // sample 2 lane of the block
                 if ((be + 1) * NAE_HOP <= p.mid_len) {
@@ -497,7 +500,7 @@ __global__ __launch_bounds__(pipe_threads(kS), kRich ? (kS == 4 ? 4 : 2) : 8) vo
             cf zs[8];
             if (active) {
                 // FFT input and pass-A twiddles in one round trip; pass A is register-only, so it runs on this side of barrier B
-                const int la = pipe_lane(lane);
+                const int la = pipe_lane<!kRich>(lane);
                 const cf* Zi = Y + la;
                 const cf* ta = twa + la;
 #pragma unroll
@@ -517,7 +520,7 @@ __global__ __launch_bounds__(pipe_threads(kS), kRich ? (kS == 4 ? 4 : 2) : 8) vo
                 const long long be = fz - kG - 3;
                 if (be >= b0) {
                     float o[4];
-                    const int lq = pipe_lane(lane);
+                    const int lq = pipe_lane<!kRich>(lane);
 #pragma unroll
                     for (int i = 3; i >= 1; i--) {
                         const int rel = j - i;                                   // < 0: an earlier step
@@ -537,7 +540,7 @@ __global__ __launch_bounds__(pipe_threads(kS), kRich ? (kS == 4 ? 4 : 2) : 8) vo
             if (kG == 1) now = __builtin_amdgcn_s_memtime();
             had = active;
             if (active) {
-                const int lb = pipe_lane(lane);
+                const int lb = pipe_lane<!kRich>(lane);
                 const FftLds L = make_fft_lds(S3, twa, w64, lb);
                 const cf* hw = reinterpret_cast<const cf*>(hann) + lb;
                 cf wn[8];                                     // synthesis window: requested behind the second transpose
