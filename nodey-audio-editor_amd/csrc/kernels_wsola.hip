@@ -101,6 +101,8 @@ __device__ __forceinline__ Best better(Best a, Best b)
     return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
 }
 
+__device__ unsigned g_td_arrivals[8 * 4 * 16];
+
 template <int CH, int NC>
 __global__ __launch_bounds__(1024 / NC, 4) void st_td_kernel(DView in, TdParams p, DOut out, float* __restrict__ mid_state,
                                                          int32_t* __restrict__ offs_dbg, long long offs_stride)
@@ -188,10 +190,28 @@ __global__ __launch_bounds__(1024 / NC, 4) void st_td_kernel(DView in, TdParams 
         window_store(wcur);
     }
     if (tid == 0) s_nan0 = 0;
+    // The workgroups of a CU (four at C5) take turns at the higher issue priority, two at a time, in time slices of 2^21 shader
+    // cycles (~1 ms): at equal priority the hardware serves them by age, they crowd the 4-waves-per-SIMD issue point together
+    // and the oldest finishes first; with two favoured at a time the search ran 11.0 -> 9.7 ms at 1024 streams, 8.6 -> 8.1 at
+    // 512, unchanged below (slices of 2^16 .. 2^20 and four-way turns: 10.2-10.3; 2^23: 11.3).  A workgroup learns its turn
+    // from an arrival counter per physical CU (never reset: only the parity is used); both read the same clock.
+    constexpr int kTurnBit = 21;
+    __shared__ int s_turn;
+    if (tid == 0) {
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 7u;
+        s_turn = (int)(atomicAdd(&g_td_arrivals[(xcc * 4 + ((hw >> 13) & 3u)) * 16 + ((hw >> 8) & 15u)], 1u) & 3u);
+    }
     __syncthreads();
+    const int my_turn = __builtin_amdgcn_readfirstlane(s_turn) & 1;
 
 #pragma unroll 1
     for (long long k = 0; k < p.nseq; k++) {
+        {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            if ((int)((now >> kTurnBit) & 1) == my_turn) __builtin_amdgcn_s_setprio(2);
+            else __builtin_amdgcn_s_setprio(0);
+        }
         // Values derived from the thread index (LDS offsets of the copy and window stores, ramp addresses ...) are invariant
         // across sequences; hoisted out of this loop they exceed the register budget and are spilled — and a scratch line
         // re-read once per sequence has left the L2 by then (measured: +10 KB of HBM reads per sequence and stream).
