@@ -28,7 +28,7 @@ struct nae_ctx {
     struct nae_wsola_cache* wsola_cache = nullptr;   // plan + workspaces of nae_wsola_block_f32 (nae_wsola.hip)
     int pv_tile = 0;             // frames per phase-vocoder tile; 0 = choose per call (nae_pick_pv_shape)
     int pv_fps = 0;              // NAE_PV_FPS=1|2|4: frames per step of the vocoder pipeline (0 = choose per call)
-    // tuning / A-B switches, read once from the environment at context creation (tools/ab.sh)
+    // tuning / A-B switches, read once from the environment at context creation (tools/ab_env.sh)
     bool dbg_st_unfused = false;     // NAE_ST_UNFUSED: WSOLA chain runs filter and cubic stage as separate launches
     int dbg_td_nc = 0;               // NAE_TD_NC=1|2|4: candidates per thread of the WSOLA search (0: by batch size)
     bool dbg_no_mix_fuse = false;    // NAE_NO_MIX_FUSE: graph4 runs mix and transposer as separate launches
