@@ -260,8 +260,13 @@ __global__ __launch_bounds__(pipe_threads(kS), kRich ? (kS == 4 ? 4 : 2) : 8) vo
         uint32_t qs[5], qp[5];                                // [4]: bin 512 (h = 0)
         {
             const uint32_t* bp = base_phase + (sc * p.phase_tiles + (long long)tile * p.phase_step) * kT1024Pad;
-            qs[0] = bp[k0]; qs[1] = bp[km0]; qs[2] = bp[k0 + 64]; qs[3] = bp[448 - k0];
-            qs[4] = bp[512];
+            if (p.base_zero) {
+#pragma unroll
+                for (int q = 0; q < 5; q++) qs[q] = 0;
+            } else {
+                qs[0] = bp[k0]; qs[1] = bp[km0]; qs[2] = bp[k0 + 64]; qs[3] = bp[448 - k0];
+                qs[4] = bp[512];
+            }
 #pragma unroll
             for (int q = 0; q < 5; q++) qp[q] = 0;
         }

@@ -769,6 +769,7 @@ static PvParams make_pv_params(const nae_stretch_plan& pl, size_t in_len, int ch
     p.phase_tiles = p.n_tiles;
     p.carry_out = nullptr;
     p.carry_frame = -1;
+    p.base_zero = 0;
     return p;
 }
 
@@ -798,8 +799,10 @@ int nae_launch_pv_phase(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig*
     if (n_needed == 0) {
         // base phase of the only synthesis tile (record 0 of each stream-channel): the carried phase, or zero
         hipError_t e = hipSuccess;
-        if (!(seg && seg->carry_in))
-            e = hipMemsetAsync(phase_ws, 0, (size_t)n_sc * p.n_tiles * kT1024Pad * sizeof(uint32_t), ctx->stream);
+        if (!(seg && seg->carry_in)) {
+            // nothing carried in and a single synthesis tile: pass 3 starts from zero by itself (PvParams::base_zero) — no memset launch
+            if (p.n_tiles != 1) e = hipMemsetAsync(phase_ws, 0, (size_t)n_sc * p.n_tiles * kT1024Pad * sizeof(uint32_t), ctx->stream);
+        }
         else if (p.n_tiles == 1)
             e = hipMemcpyAsync(phase_ws, seg->carry_in, (size_t)n_sc * kT1024Pad * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream);
         else
@@ -841,6 +844,7 @@ int nae_launch_pv_synth(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig*
     const long long cnt = p.f_stop - p.f_origin;
     p.phase_step = tile / phase_tile;
     p.phase_tiles = (int)((cnt + phase_tile - 1) / phase_tile);
+    p.base_zero = (p.n_tiles == 1 && p.phase_tiles == 1 && !(seg && seg->carry_in)) ? 1 : 0;
     if (seg && seg->carry_by_synth && seg->carry_out) {
         if (p.n_tiles != 1) return nae_fail(ctx, NAE_ERR_INVALID, "carry_by_synth needs a single synthesis tile");
         p.carry_out = seg->carry_out;

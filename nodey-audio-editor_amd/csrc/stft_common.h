@@ -30,6 +30,7 @@ struct PvParams {
     int skip_from;        // pass 1 only: tiles >= skip_from are not analysed (their sums are not needed)
     int phase_step;       // pass 3 only: pass 1 ran on tiles `phase_step` times shorter (more waves for the same frames);
     int phase_tiles;      //              the base phase of tile t is record t * phase_step of `phase_tiles` per stream-channel
+    int base_zero;        // pass 3: the base phase of every tile is zero (one tile per stream-channel, nothing carried in): no workspace read
     uint32_t* carry_out;  // pass 3, optional: receives the synthesis phase behind frame `carry_frame`, [stream-channel][520] (a continued
     long long carry_frame; //             stream whose segment is ONE tile: no pass 1 is needed just to carry the phase on)
 };
