@@ -79,3 +79,17 @@ def test_fails_loudly_without_gpu(nae):
         pytest.skip("a GPU is present")
     with pytest.raises(nae.NaeError):
         nae.Context(0)
+
+
+def test_no_diagnostic_scaffolding_in_product_sources():
+    """the in-kernel stamp scaffolding of the vocoder pipeline lives in tools/pipe_stamps/ and is spliced into a COPY of the kernel
+    source by make_variant.sh; the product translation units carry marker comments only"""
+    csrc = os.path.join(ROOT, "nodey-audio-editor_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".h")):
+            src = open(os.path.join(csrc, f), errors="replace").read()
+            assert "g_pipe_stamps" not in src and "NAE_PIPE_STAMPS" not in src and "nae_debug_read_pipe" not in src, f
+    pipe = open(os.path.join(csrc, "kernels_pvpipe.hip")).read()
+    assert pipe.count("/*A*/") == 3 and pipe.count("/*B*/") == 3 and "/*pipe:begin*/" in pipe and "/*pipe:r1-end*/" in pipe
+    inc = open(os.path.join(ROOT, "tools", "pipe_stamps", "stamps.inc")).read()
+    assert "g_pipe_stamps" in inc
