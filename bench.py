@@ -188,10 +188,11 @@ def main():
         "mix_resample_tile_kernel": 24.0 * sf + 8.0 * sf * mid_ratio,   # the mix node's 24 B + the transposed signal once
         "pv_phase_kernel": 8.0 * sf,                     # re-read of the input (pass 1); output negligible
         "pv_scan_kernel": 0.0,
-        "pv_synth_kernel": 8.0 * sf + 8.0 * sf * mid_ratio,   # input once + stretched signal once
+        "pv_pipe_kernel": 8.0 * sf + 8.0 * sf * mid_ratio,    # input once + stretched signal once
         "resample_kernel": 8.0 * sf * mid_ratio + 8.0 * sf,   # stretched signal once + output once
         "resample_tile_kernel": 8.0 * sf * mid_ratio + 8.0 * sf,
-        "spectrum_kernel": 8.0 * sf + 2 * BINS * 4.0 * n_streams * F,   # 24.03 B per sample-frame
+        "spectrum_stereo_kernel": 8.0 * sf + 2 * BINS * 4.0 * n_streams * F,   # 24.03 B per sample-frame
+        "spectrum_kernel": 8.0 * sf + 2 * BINS * 4.0 * n_streams * F,          # (generic layouts)
     }
     roofline = None
     kern_report = {}

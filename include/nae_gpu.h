@@ -51,8 +51,16 @@ typedef struct nae_spectrum nae_spectrum;
 /* ------------------------------------------------------------------ context / plumbing */
 int nae_abi_version(void);
 int nae_device_count(void);
-/* One GPU per process: every context of a process must name the same device (a second device returns
- * NAE_ERR_UNSUPPORTED); several contexts on that device are fine — each has its own stream, so their work overlaps. */
+/* Devices.  A process may hold contexts on SEVERAL devices (the reference runs every node of a graph in one process on one
+ * thread, src/infra/runner.cpp:65-83,142-154, so the drop-in reaches all GPUs of the node from there): a context remembers
+ * its device, and every entry point that allocates, launches or records selects that device for the calling thread when the
+ * thread's current HIP device differs — and leaves it selected.  `device` outside [0, nae_device_count()) returns
+ * NAE_ERR_INVALID.  Several contexts on one device are fine — each has its own stream, so their work overlaps.
+ * (More than one device per process is exercised on one-GPU boxes only, through two contexts on device 0 and the
+ * rejection of device 1: N > 1 devices from one process are UNMEASURED on hardware.)
+ * Threads.  The library keeps no process-global mutable state.  ONE thread at a time drives a given context and the
+ * handles / events created from it; different contexts may be created, driven and destroyed from different threads
+ * concurrently.  nae_event_query / nae_poll may be called from the thread that drives the context. */
 int nae_ctx_create(int device, nae_ctx** out);
 int nae_ctx_destroy(nae_ctx* ctx);
 int nae_ctx_set_stream(nae_ctx* ctx, void* hip_stream); /* borrow a hipStream_t (e.g. torch's current stream) */
@@ -75,6 +83,13 @@ int nae_memset(nae_ctx* ctx, void* dst, int value, size_t bytes);
 
 int nae_event_create(nae_ctx* ctx, nae_event** ev);
 int nae_event_record(nae_ctx* ctx, nae_event* ev);      /* on the ctx stream */
+/* 1 = everything enqueued before the last nae_event_record(ev) has completed, 0 = still pending, < 0 = error; never blocks.
+ * The wait a node's fiber spins on for ITS OWN batch (include/infra/processor.hpp:108-113 — process_payload of one node — while
+ * other nodes' work may still be queued on the same or another context): record behind the batch, poll, yield. */
+int nae_event_query(nae_event* ev);
+/* makes everything enqueued on ctx's stream AFTER this call wait for the work captured by the last record of `ev`
+ * (hipStreamWaitEvent): a device-side dependency between two contexts of the same device, nothing blocks on the host */
+int nae_ctx_wait_event(nae_ctx* ctx, nae_event* ev);
 int nae_event_elapsed_ms(nae_event* start, nae_event* stop, float* ms); /* synchronises on `stop` */
 int nae_event_destroy(nae_event* ev);
 
@@ -295,6 +310,9 @@ typedef struct nae_graph4 {
     size_t n_streams;
 } nae_graph4;
 int nae_graph4_run(nae_ctx* ctx, const nae_graph4* g);
+/* the same graph, only the stages selected by `mask`: 1 = mix node (+ the pitch node's transposer when it runs first),
+ * 2 = the rest of the pitch node, 4 = spectrum node.  Scheduling experiments and tests; 7 == nae_graph4_run on one stream. */
+int nae_debug_graph4_stages(nae_ctx* ctx, const nae_graph4* g, int mask);
 
 #ifdef __cplusplus
 }

@@ -18,6 +18,7 @@ EXPORTED_SYMBOLS = [
     "nae_abi_version", "nae_device_count", "nae_ctx_create", "nae_ctx_destroy", "nae_ctx_set_stream",
     "nae_ctx_stream", "nae_sync", "nae_poll", "nae_last_error", "nae_device_name", "nae_malloc", "nae_free",
     "nae_memcpy_h2d", "nae_memcpy_d2h", "nae_memcpy_d2d", "nae_memset", "nae_event_create", "nae_event_record",
+    "nae_event_query", "nae_ctx_wait_event", "nae_debug_graph4_stages",
     "nae_event_elapsed_ms", "nae_event_destroy", "nae_prof_enable", "nae_prof_reset", "nae_prof_get",
     "nae_malloc_host", "nae_free_host", "nae_debug_clock_ghz", "nae_debug_diff_u32", "nae_fill_uniform_f32", "nae_gain_f32", "nae_gain_s16", "nae_gain_s32", "nae_gain_frame",
     "nae_deinterleave_f32", "nae_interleave_f32", "nae_copy_sig_f32", "nae_gain_sig_f32", "nae_amix_f32",
@@ -113,6 +114,7 @@ def load_library() -> C.CDLL:
         "nae_memcpy_h2d": (i, [vp, vp, vp, sz]), "nae_memcpy_d2h": (i, [vp, vp, vp, sz]),
         "nae_memcpy_d2d": (i, [vp, vp, vp, sz]), "nae_memset": (i, [vp, vp, i, sz]),
         "nae_event_create": (i, [vp, P(vp)]), "nae_event_record": (i, [vp, vp]),
+        "nae_event_query": (i, [vp]), "nae_ctx_wait_event": (i, [vp, vp]), "nae_debug_graph4_stages": (i, [vp, P(Graph4), i]),
         "nae_event_elapsed_ms": (i, [vp, vp, P(f)]), "nae_event_destroy": (i, [vp]),
         "nae_prof_enable": (i, [vp, i]), "nae_prof_reset": (i, [vp]),
         "nae_prof_get": (i, [vp, i, C.c_char_p, sz, P(d), P(C.c_uint64)]),
@@ -273,6 +275,17 @@ class Context:
     def record(self, ev) -> None:
         self._ck(self.lib.nae_event_record(self.h, ev))
 
+    def query(self, ev) -> int:
+        """1 = the work in front of the event's last record is done, 0 = pending (never blocks)"""
+        rc = self.lib.nae_event_query(ev)
+        if rc < 0:
+            raise NaeError(f"nae_event_query failed: {rc}")
+        return rc
+
+    def wait_event(self, ev) -> None:
+        """work enqueued on this context from now on waits (on the device) for the event's last record"""
+        self._ck(self.lib.nae_ctx_wait_event(self.h, ev))
+
     def elapsed_ms(self, a, b) -> float:
         ms = C.c_float()
         rc = self.lib.nae_event_elapsed_ms(a, b, C.byref(ms))
@@ -425,3 +438,7 @@ class Context:
     # -- graph
     def graph4(self, g: Graph4):
         self._ck(self.lib.nae_graph4_run(self.h, C.byref(g)))
+
+    def graph4_stages(self, g: Graph4, mask: int):
+        """stages of the graph: 1 = mix (+ transposer when first), 2 = rest of the pitch node, 4 = spectrum"""
+        self._ck(self.lib.nae_debug_graph4_stages(self.h, C.byref(g), mask))

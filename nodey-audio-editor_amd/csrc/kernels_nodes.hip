@@ -548,6 +548,7 @@ int nae_debug_clock_ghz(nae_ctx* ctx, double* ghz)
     if (!ctx || !ghz) return NAE_ERR_INVALID;
     const int blocks = 1024, waves = blocks * 4;
     unsigned long long* d = nullptr;
+    (void)nae_use_device(ctx);
     hipError_t e = hipMalloc((void**)&d, sizeof(unsigned long long) * 2 * waves);
     if (e != hipSuccess) return nae_check(ctx, e, "hipMalloc(clock probe)");
     hipLaunchKernelGGL(clock_probe_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d, 20000);

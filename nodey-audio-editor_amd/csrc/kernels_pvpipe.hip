@@ -589,22 +589,26 @@ __global__ __launch_bounds__(pipe_threads(kS), kRich ? (kS == 4 ? 4 : 2) : 8) vo
 using namespace nae;
 
 template <int kG, int kS, bool kRich>
-static void pipe_launch(nae_ctx* ctx, unsigned groups, const SigViewD& src, const PvParams& p, long long n_sc, const uint32_t* phase_ws,
+static int pipe_launch(nae_ctx* ctx, unsigned groups, const SigViewD& src, const PvParams& p, long long n_sc, const uint32_t* phase_ws,
                         const OutViewD& out, const Tables& tb, bool unit_stride)
 {
-    // more than 64 KiB of dynamic LDS needs the attribute (once per instantiation)
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pv_pipe_kernel<true, kG, kS, kRich>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pipe_lds(kG, kS));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pv_pipe_kernel<false, kG, kS, kRich>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pipe_lds(kG, kS));
-        attr_done = true;
+    // more than 64 KiB of dynamic LDS needs the attribute: once per instantiation and DEVICE, so the flag lives in the context
+    // (no process-global launch state: contexts of different devices, or driven by different threads, do not share it)
+    constexpr unsigned bit = 1u << ((kG == 1 ? 0 : kG == 2 ? 1 : 2) * 2 + (kRich ? 1 : 0));
+    if (!(ctx->pv_attr_done & bit)) {
+        (void)nae_use_device(ctx);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pv_pipe_kernel<true, kG, kS, kRich>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pipe_lds(kG, kS));
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pv_pipe_kernel<false, kG, kS, kRich>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pipe_lds(kG, kS));
+        if (e != hipSuccess) return nae_check(ctx, e, "hipFuncSetAttribute(pv_pipe_kernel)");
+        ctx->pv_attr_done |= bit;
     }
     if (unit_stride)
-        NAE_KLAUNCH(ctx, "pv_synth_kernel", (pv_pipe_kernel<true, kG, kS, kRich>), dim3(groups), dim3(pipe_threads(kS)), pipe_lds(kG, kS), ctx->stream, src, p,
+        NAE_KLAUNCH(ctx, "pv_pipe_kernel", (pv_pipe_kernel<true, kG, kS, kRich>), dim3(groups), dim3(pipe_threads(kS)), pipe_lds(kG, kS), ctx->stream, src, p,
                     n_sc, phase_ws, out, tb);
     else
-        NAE_KLAUNCH(ctx, "pv_synth_kernel", (pv_pipe_kernel<false, kG, kS, kRich>), dim3(groups), dim3(pipe_threads(kS)), pipe_lds(kG, kS), ctx->stream, src, p,
+        NAE_KLAUNCH(ctx, "pv_pipe_kernel", (pv_pipe_kernel<false, kG, kS, kRich>), dim3(groups), dim3(pipe_threads(kS)), pipe_lds(kG, kS), ctx->stream, src, p,
                     n_sc, phase_ws, out, tb);
+    return NAE_OK;
 }
 
 // frames_per_step: 1 = one stream-channel per slot; 2 / 4 = frame-interleaved (two / one stream-channel per four slots)
@@ -622,10 +626,12 @@ int nae_launch_pv_pipe(nae_ctx* ctx, const PvParams& p, const SigViewD& src, lon
     Tables tb{ctx->d_w512, ctx->d_t1024, ctx->d_hann};
     // kRich: at most one workgroup per CU anyway (the frame-interleaved modes by their LDS; four slots per workgroup on a grid
     // of at most n_cu workgroups) -> 128 VGPRs per wave, tables in registers
-    const bool rich1 = frames_per_step == 1 && groups <= (long long)ctx->n_cu;
-    if (frames_per_step == 1 && rich1) pipe_launch<1, 4, true>(ctx, (unsigned)groups, src, p, n_sc, phase_ws, out, tb, unit_stride);
-    else if (frames_per_step == 1) pipe_launch<1, 4, false>(ctx, (unsigned)groups, src, p, n_sc, phase_ws, out, tb, unit_stride);
-    else if (frames_per_step == 2) pipe_launch<2, 4, true>(ctx, (unsigned)groups, src, p, n_sc, phase_ws, out, tb, unit_stride);
-    else pipe_launch<4, 4, true>(ctx, (unsigned)groups, src, p, n_sc, phase_ws, out, tb, unit_stride);
+    const bool rich1 = frames_per_step == 1 && groups <= (long long)ctx->n_cu && !ctx->pv_lean;
+    int rc;
+    if (frames_per_step == 1 && rich1) rc = pipe_launch<1, 4, true>(ctx, (unsigned)groups, src, p, n_sc, phase_ws, out, tb, unit_stride);
+    else if (frames_per_step == 1) rc = pipe_launch<1, 4, false>(ctx, (unsigned)groups, src, p, n_sc, phase_ws, out, tb, unit_stride);
+    else if (frames_per_step == 2) rc = pipe_launch<2, 4, true>(ctx, (unsigned)groups, src, p, n_sc, phase_ws, out, tb, unit_stride);
+    else rc = pipe_launch<4, 4, true>(ctx, (unsigned)groups, src, p, n_sc, phase_ws, out, tb, unit_stride);
+    if (rc) return rc;
     return nae_check(ctx, hipGetLastError(), "pv_pipe_kernel");
 }

@@ -735,7 +735,7 @@ int nae_launch_spectrum(nae_ctx* ctx, const nae_sig* src, size_t T, int ch, size
         const int chunk = spec_pick_chunk((long long)F, (long long)n_streams, ctx->n_cu);
         const long long chunks = ((long long)F + chunk - 1) / chunk;
         const long long citems = chunks * (long long)n_streams;
-        NAE_KLAUNCH(ctx, "spectrum_kernel", spectrum_stereo_kernel, dim3((unsigned)((citems + kWaves - 1) / kWaves)), dim3(kThreads),
+        NAE_KLAUNCH(ctx, "spectrum_stereo_kernel", spectrum_stereo_kernel, dim3((unsigned)((citems + kWaves - 1) / kWaves)), dim3(kThreads),
                     kLdsSpecStereo, ctx->stream, static_cast<const float*>(src->base), (long long)src->stream_stride,
                     (long long)F, chunks, chunk, citems, dst, (long long)dst_stream_stride, tb);
     }

@@ -60,7 +60,7 @@ static void prof_collect(nae_ctx* ctx)
 int nae_ws_reserve(nae_ctx* ctx, void** p, size_t* have, size_t want)
 {
     if (*have >= want && *p) return NAE_OK;
-    (void)hipSetDevice(ctx->device);
+    (void)nae_use_device(ctx);
     if (*p) {
         hipError_t e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) return nae_check(ctx, e, "hipStreamSynchronize");
@@ -129,6 +129,7 @@ static void build_rs_table(double rate_eff, std::vector<float>& tab)
 int nae_ensure_rs_table(nae_ctx* ctx, double rate_eff)
 {
     if (ctx->d_rs_tab && ctx->rs_tab_rate == rate_eff) return NAE_OK;
+    (void)nae_use_device(ctx);
     if (!ctx->d_rs_tab) {
         hipError_t e = hipMalloc((void**)&ctx->d_rs_tab, (NAE_RS_PHASES + 1) * NAE_RS_TAPS * sizeof(float));
         if (e != hipSuccess) return nae_check(ctx, e, "hipMalloc(rs table)");
@@ -189,22 +190,20 @@ int nae_device_count(void)
     return n;
 }
 
-// One GPU per process (the deployment model: one process per GPU, torch.distributed / RCCL between them).  Allocations and
-// launches go to the calling thread's CURRENT device, so contexts on two devices inside one process would need a device
-// switch at every entry point; instead a second device is refused, and the entry points that allocate re-select the
-// context's device in case another library (torch) changed the thread's current one.
-static int g_nae_device = -1;
-
+// Several GPUs per process: the reference runs every node of a graph in ONE process on ONE thread
+// (/root/reference/src/infra/runner.cpp:65-83,142-154), so the drop-in must reach all devices of the node from there.  A context
+// remembers its device; allocations and launches go to the calling thread's CURRENT device in HIP, so every entry point selects
+// the context's device first when it differs (nae_use_device: one hipGetDevice on the fast path) and leaves it selected.
+// No process-global state: launch attributes are tracked per context, so contexts may be created and driven from different
+// threads as long as ONE thread at a time drives a given context and its handles (include/nae_gpu.h, "Threads").
 int nae_ctx_create(int device, nae_ctx** out)
 {
     if (!out) return NAE_ERR_INVALID;
     *out = nullptr;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return NAE_ERR_HIP;
-    if (device < 0 || device >= n) return NAE_ERR_INVALID;
-    if (g_nae_device >= 0 && g_nae_device != device) return NAE_ERR_UNSUPPORTED;
+    if (device < 0 || device >= n) return NAE_ERR_INVALID;          // no such device
     if (hipSetDevice(device) != hipSuccess) return NAE_ERR_HIP;
-    g_nae_device = device;
     nae_ctx* ctx = new (std::nothrow) nae_ctx();
     if (!ctx) return NAE_ERR_NOMEM;
     ctx->device = device;
@@ -223,6 +222,7 @@ int nae_ctx_create(int device, nae_ctx** out)
     ctx->dbg_st_unfused = getenv("NAE_ST_UNFUSED") != nullptr;
     ctx->dbg_rs_direct = getenv("NAE_RS_DIRECT") != nullptr;
     ctx->dbg_spec_generic = getenv("NAE_SPEC_GENERIC") != nullptr;
+    ctx->pv_lean = getenv("NAE_PV_LEAN") != nullptr;
     std::vector<nae::cf> w512, t1024;
     std::vector<float> hann;
     build_tables(w512, t1024, hann);
@@ -240,7 +240,7 @@ int nae_ctx_create(int device, nae_ctx** out)
 int nae_ctx_destroy(nae_ctx* ctx)
 {
     if (!ctx) return NAE_OK;
-    (void)hipSetDevice(ctx->device);
+    (void)nae_use_device(ctx);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     prof_collect(ctx);
     if (ctx->d_w512) (void)hipFree(ctx->d_w512);
@@ -290,7 +290,7 @@ int nae_malloc(nae_ctx* ctx, size_t bytes, void** dptr)
     if (!ctx || !dptr) return NAE_ERR_INVALID;
     *dptr = nullptr;
     if (bytes == 0) bytes = 16;
-    (void)hipSetDevice(ctx->device);
+    (void)nae_use_device(ctx);
     hipError_t e = hipMalloc(dptr, bytes);
     if (e != hipSuccess) { nae_check(ctx, e, "hipMalloc"); return NAE_ERR_NOMEM; }
     return NAE_OK;
@@ -305,7 +305,7 @@ int nae_malloc_host(nae_ctx* ctx, size_t bytes, void** hptr)
     if (!ctx || !hptr) return NAE_ERR_INVALID;
     *hptr = nullptr;
     if (bytes == 0) bytes = 16;
-    (void)hipSetDevice(ctx->device);
+    (void)nae_use_device(ctx);
     hipError_t e = hipHostMalloc(hptr, bytes, hipHostMallocDefault);
     if (e != hipSuccess) { nae_check(ctx, e, "hipHostMalloc"); return NAE_ERR_NOMEM; }
     return NAE_OK;
@@ -341,6 +341,7 @@ int nae_event_create(nae_ctx* ctx, nae_event** ev)
     if (!ctx || !ev) return NAE_ERR_INVALID;
     nae_event* e = new (std::nothrow) nae_event();
     if (!e) return NAE_ERR_NOMEM;
+    (void)nae_use_device(ctx);
     if (hipEventCreate(&e->ev) != hipSuccess) { delete e; return NAE_ERR_HIP; }
     *ev = e;
     return NAE_OK;
@@ -349,6 +350,19 @@ int nae_event_record(nae_ctx* ctx, nae_event* ev)
 {
     if (!ctx || !ev) return NAE_ERR_INVALID;
     return nae_check(ctx, hipEventRecord(ev->ev, ctx->stream), "hipEventRecord");
+}
+int nae_event_query(nae_event* ev)
+{
+    if (!ev) return NAE_ERR_INVALID;
+    const hipError_t e = hipEventQuery(ev->ev);
+    if (e == hipSuccess) return 1;
+    if (e == hipErrorNotReady) return 0;
+    return NAE_ERR_HIP;
+}
+int nae_ctx_wait_event(nae_ctx* ctx, nae_event* ev)
+{
+    if (!ctx || !ev) return NAE_ERR_INVALID;
+    return nae_check(ctx, hipStreamWaitEvent(ctx->stream, ev->ev, 0), "hipStreamWaitEvent");
 }
 int nae_event_elapsed_ms(nae_event* start, nae_event* stop, float* ms)
 {
@@ -449,8 +463,11 @@ struct nae_mix_front {
     float va, vb;
 };
 
+// stages: bit 0 = the front stage (the mix node, and the transposer when it runs first), bit 1 = everything behind it
+// (nae_debug_graph4_stages: scheduling experiments run the two from separate calls; the intermediate signal stays in the
+// context's workspace between them).
 static int stretch_block_impl(nae_ctx* ctx, double rate, double pitch, const nae_sig* src, size_t in_len, int ch, size_t n_streams,
-                              const nae_sig* dst, const nae_mix_front* front)
+                              const nae_sig* dst, const nae_mix_front* front, int stages = 3)
 {
     if (!ctx) return NAE_ERR_INVALID;
     int rc;
@@ -460,7 +477,7 @@ static int stretch_block_impl(nae_ctx* ctx, double rate, double pitch, const nae
     rc = nae_stretch_plan_make(rate, pitch, in_len, &pl);
     if (rc) return nae_fail(ctx, rc, "rate/pitch outside the supported range");
     // the mix node in front: fused into the transposer when that runs first, else its own launch (src = its output)
-    bool mix_pending = front != nullptr;
+    bool mix_pending = front != nullptr && (stages & 1);
     auto run_mix = [&]() -> int {
         if (!mix_pending) return NAE_OK;
         mix_pending = false;
@@ -471,7 +488,7 @@ static int stretch_block_impl(nae_ctx* ctx, double rate, double pitch, const nae
     if (n_streams == 0 || pl.out_len == 0) return run_mix();
     if (!pl.pv_on && !pl.rs_on) {
         if ((rc = run_mix())) return rc;
-        return nae_launch_copy_sig(ctx, src, dst, in_len, ch, n_streams, false, 1.0f);
+        return (stages & 2) ? nae_launch_copy_sig(ctx, src, dst, in_len, ch, n_streams, false, 1.0f) : NAE_OK;
     }
 
     const size_t mid_stride = (pl.mid_len + 3) & ~(size_t)3;
@@ -490,7 +507,10 @@ static int stretch_block_impl(nae_ctx* ctx, double rate, double pitch, const nae
     size_t pv_in_len = in_len;
     const nae_sig* pv_dst = dst;
     long long pv_out_len = (long long)pl.out_len;
-    if (pl.rs_first) {
+    if (pl.rs_first && !(stages & 1)) {
+        pv_src = &mid;
+        pv_in_len = pl.mid_len;
+    } else if (pl.rs_first) {
         rc = 1;
         if (mix_pending && ch == 2) {
             rc = nae_launch_mix_resample(ctx, &pl, front->a, front->b, front->va, front->vb, src, in_len, n_streams, ctx->d_rs_tab, &mid);
@@ -509,6 +529,7 @@ static int stretch_block_impl(nae_ctx* ctx, double rate, double pitch, const nae
         pv_out_len = (long long)pl.mid_len;
     }
     if ((rc = run_mix())) return rc;     // vocoder first / transposer only: the mix is a launch of its own
+    if (!(stages & 2)) return NAE_OK;
     if (pl.pv_on) {
         int phase_tile = 0, fps = 1;
         const int tile = nae_pick_pv_shape(ctx, pl.frames, n_streams * ch, &phase_tile, &fps);
@@ -598,21 +619,36 @@ int nae_spectrum_block_f32(nae_ctx* ctx, const nae_sig* src, size_t T, int ch, s
 }
 
 // ------------------------------------------------------------------------------------------------ graph
-int nae_graph4_run(nae_ctx* ctx, const nae_graph4* g)
+// mask: 1 = mix node (+ the pitch node's transposer when that runs first), 2 = the rest of the pitch node, 4 = spectrum node
+static int graph4_stages(nae_ctx* ctx, const nae_graph4* g, int mask)
 {
-    if (!ctx || !g) return NAE_ERR_INVALID;
     // node 1+2: the two inputs feed the 2-input mixer (audio-amix.cpp:86-324 with input_num = 2)
     // node 3: pitch (audio-velocity.cpp:462-477).  When its transposer runs first the mix happens inside that launch
     // (same arithmetic, same mix_out contents); otherwise the mix is launched on its own in front.
     if (!g->in_a.base || !g->in_b.base || !g->mix_out.base) return nae_fail(ctx, NAE_ERR_INVALID, "nae_graph4_run: null signal");
     const nae_mix_front front{&g->in_a, &g->in_b, g->vol_a, g->vol_b};
-    int rc = stretch_block_impl(ctx, g->rate, g->pitch, &g->mix_out, g->S, 2, g->n_streams, &g->pitch_out, &front);
-    if (rc) return rc;
+    int rc = NAE_OK;
+    if (mask & 3) rc = stretch_block_impl(ctx, g->rate, g->pitch, &g->mix_out, g->S, 2, g->n_streams, &g->pitch_out, &front, mask & 3);
+    if (rc || !(mask & 4)) return rc;
     nae_stretch_plan pl;
     rc = nae_stretch_plan_make(g->rate, g->pitch, g->S, &pl);
     if (rc) return rc;
     // node 4: spectrum
     return nae_spectrum_block_f32(ctx, &g->pitch_out, pl.out_len, 2, g->n_streams, g->spec_out, g->spec_stream_stride);
+}
+
+int nae_graph4_run(nae_ctx* ctx, const nae_graph4* g)
+{
+    if (!ctx || !g) return NAE_ERR_INVALID;
+    (void)nae_use_device(ctx);
+    return graph4_stages(ctx, g, 7);
+}
+
+int nae_debug_graph4_stages(nae_ctx* ctx, const nae_graph4* g, int mask)
+{
+    if (!ctx || !g) return NAE_ERR_INVALID;
+    (void)nae_use_device(ctx);
+    return graph4_stages(ctx, g, mask);
 }
 
 } // extern "C"

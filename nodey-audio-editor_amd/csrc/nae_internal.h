@@ -35,6 +35,10 @@ struct nae_ctx {
     bool dbg_rs_single = false;      // NAE_RS_SINGLE: one stream per transposer workgroup (no coefficient sharing)
     bool dbg_rs_direct = false;      // NAE_RS_DIRECT: direct (unstaged) transposer kernel
     bool dbg_spec_generic = false;   // NAE_SPEC_GENERIC: skip the interleaved-stereo spectrum fast path
+    bool pv_lean = false;            // NAE_PV_LEAN: the vocoder pipeline keeps its 64-VGPR shape even when one workgroup per CU would allow
+                                     // 128 (leaves half of the register file and 94 KB of LDS to a co-resident kernel: tools/coresidency.py)
+    // per-context, per-device launch state (a kernel attribute is set once per device: the flag lives with the context's device)
+    unsigned pv_attr_done = 0;       // bit per pv_pipe_kernel instantiation whose dynamic-LDS attribute has been set through this context
     // optional per-kernel timing (hipEvent pairs on the ctx stream), used by bench.py for the roofline line
     bool prof_on = false;
     struct ProfSlot { const char* name; double total_ms; uint64_t launches; };
@@ -50,8 +54,19 @@ struct NaeProfScope {
     ~NaeProfScope();
 };
 
+// Several devices in one process: a context remembers its device and every entry point that allocates, launches or records
+// selects it when the calling thread's current device differs (one hipGetDevice on the fast path).  The thread's current device is
+// left on the context's.
+static inline int nae_use_device(nae_ctx* ctx)
+{
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur == ctx->device) return 0;
+    return hipSetDevice(ctx->device) == hipSuccess ? 0 : -3 /* NAE_ERR_HIP */;
+}
+
 #define NAE_KLAUNCH(ctx, name_str, ...)          \
     do {                                          \
+        (void)nae_use_device(ctx);                \
         NaeProfScope nae_ps_(ctx, name_str);      \
         hipLaunchKernelGGL(__VA_ARGS__);          \
     } while (0)

@@ -283,6 +283,7 @@ extern "C" {
 int nae_stretch_create(nae_ctx* ctx, int sample_rate, int channels, float rate, float pitch, nae_stretch** h)
 {
     if (!ctx || !h) return NAE_ERR_INVALID;
+    (void)nae_use_device(ctx);
     *h = nullptr;
     // audio-velocity.cpp:371-379 rejects rates outside 8..48 kHz for SoundTouch; the vocoder has no such
     // limit, but the drop-in keeps the reference's envelope (lift it with sample_rate = 0).
@@ -306,6 +307,7 @@ int nae_stretch_create(nae_ctx* ctx, int sample_rate, int channels, float rate, 
 static int stretch_append(nae_stretch* h, const float* p, size_t S, bool host)
 {
     if (!h || (S && !p)) return NAE_ERR_INVALID;
+    (void)nae_use_device(h->ctx);
     if (h->flushed) return nae_fail(h->ctx, NAE_ERR_STATE, "put after flush");
     if (S == 0) return NAE_OK;
     const size_t n = S * h->ch;
@@ -328,6 +330,7 @@ int nae_stretch_put_host(nae_stretch* h, const float* interleaved, size_t S) { r
 int nae_stretch_flush(nae_stretch* h)
 {
     if (!h) return NAE_ERR_INVALID;
+    (void)nae_use_device(h->ctx);
     if (h->flushed) return NAE_OK;
     h->flushed = true;
     return stretch_process(h);
@@ -338,6 +341,7 @@ size_t nae_stretch_available(nae_stretch* h) { return h ? h->out_total - h->out_
 static int stretch_take(nae_stretch* h, float* dst, size_t max_frames, size_t* got, bool host)
 {
     if (!h || !got || (max_frames && !dst)) return NAE_ERR_INVALID;
+    (void)nae_use_device(h->ctx);
     size_t n = h->out_total - h->out_read;
     if (n > max_frames) n = max_frames;
     *got = n;
@@ -361,6 +365,7 @@ int nae_stretch_receive_host(nae_stretch* h, float* dst, size_t max_frames, size
 int nae_stretch_destroy(nae_stretch* h)
 {
     if (!h) return NAE_OK;
+    (void)nae_use_device(h->ctx);
     (void)hipStreamSynchronize(h->ctx->stream);
     fifo_free(h->in);
     fifo_free(h->mid);
@@ -375,6 +380,7 @@ int nae_stretch_destroy(nae_stretch* h)
 int nae_spectrum_create(nae_ctx* ctx, int n_fft, int hop, int channels, nae_spectrum** h)
 {
     if (!ctx || !h) return NAE_ERR_INVALID;
+    (void)nae_use_device(ctx);
     *h = nullptr;
     if (n_fft != NAE_FFT_N || hop != NAE_HOP) return nae_fail(ctx, NAE_ERR_UNSUPPORTED, "only N = 1024, hop = 256 is implemented");
     if (channels != 1 && channels != 2) return nae_fail(ctx, NAE_ERR_INVALID, "channel count must be 1 or 2");
@@ -389,6 +395,7 @@ int nae_spectrum_create(nae_ctx* ctx, int n_fft, int hop, int channels, nae_spec
 int nae_spectrum_put(nae_spectrum* h, const float* interleaved, size_t S)
 {
     if (!h || (S && !interleaved)) return NAE_ERR_INVALID;
+    (void)nae_use_device(h->ctx);
     if (S == 0) return NAE_OK;
     nae_ctx* ctx = h->ctx;
     const size_t n = S * h->ch;
@@ -443,6 +450,7 @@ size_t nae_spectrum_available(nae_spectrum* h) { return h ? h->out_frames - h->o
 int nae_spectrum_receive(nae_spectrum* h, float* dst, size_t max_frames, size_t* got)
 {
     if (!h || !got || (max_frames && !dst)) return NAE_ERR_INVALID;
+    (void)nae_use_device(h->ctx);
     size_t n = h->out_frames - h->out_read;
     if (n > max_frames) n = max_frames;
     *got = n;
@@ -457,6 +465,7 @@ int nae_spectrum_receive(nae_spectrum* h, float* dst, size_t max_frames, size_t*
 int nae_spectrum_destroy(nae_spectrum* h)
 {
     if (!h) return NAE_OK;
+    (void)nae_use_device(h->ctx);
     (void)hipStreamSynchronize(h->ctx->stream);
     devbuf_free(h->pending);
     devbuf_free(h->pending_alt);

@@ -240,6 +240,7 @@ extern "C" {
 int nae_swr_create(nae_ctx* ctx, int in_fmt, int in_rate, int in_channels, int out_rate, nae_swr** h)
 {
     if (!ctx || !h) return NAE_ERR_INVALID;
+    (void)nae_use_device(ctx);
     *h = nullptr;
     switch (in_fmt) {
     case NAE_FMT_S16: case NAE_FMT_S32: case NAE_FMT_FLT: case NAE_FMT_S16P: case NAE_FMT_S32P: case NAE_FMT_FLTP: break;
@@ -335,6 +336,7 @@ static int swr_convert_common(nae_swr* h, const void* const* planes, size_t n_in
 int nae_swr_convert_host(nae_swr* h, const void* const* planes, size_t n_in, float* outL, float* outR, size_t max_out, size_t* n_out)
 {
     if (!h || !n_out || (max_out && (!outL || !outR))) return NAE_ERR_INVALID;
+    (void)nae_use_device(h->ctx);
     nae_ctx* ctx = h->ctx;
     *n_out = 0;
     int rc;
@@ -360,6 +362,7 @@ int nae_swr_convert_host(nae_swr* h, const void* const* planes, size_t n_in, flo
 int nae_swr_convert(nae_swr* h, const void* const* planes, size_t n_in, float* outL, float* outR, size_t max_out, size_t* n_out)
 {
     if (!h || !n_out || (max_out && (!outL || !outR))) return NAE_ERR_INVALID;
+    (void)nae_use_device(h->ctx);
     *n_out = 0;
     int rc;
     if ((rc = swr_convert_common(h, planes, n_in))) return rc;
@@ -369,6 +372,7 @@ int nae_swr_convert(nae_swr* h, const void* const* planes, size_t n_in, float* o
 int nae_swr_destroy(nae_swr* h)
 {
     if (!h) return NAE_OK;
+    (void)nae_use_device(h->ctx);
     (void)hipStreamSynchronize(h->ctx->stream);
     fifo_free(h->in);
     fifo_free(h->out);

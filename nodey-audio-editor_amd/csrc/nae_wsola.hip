@@ -258,6 +258,7 @@ int nae_wsola_block_f32(nae_ctx* ctx, int sample_rate, double rate, double pitch
                         size_t n_streams, const nae_sig* dst, int32_t* offsets_dbg)
 {
     if (!ctx) return NAE_ERR_INVALID;
+    (void)nae_use_device(ctx);
     if (!src || !dst || !src->base || !dst->base) return nae_fail(ctx, NAE_ERR_INVALID, "nae_wsola_block_f32: null signal");
     nae_wsola_cache* wc = cache_of(ctx);
     if (!wc) return nae_fail(ctx, NAE_ERR_NOMEM, "plan cache");
@@ -515,6 +516,7 @@ extern "C" {
 int nae_wsola_create(nae_ctx* ctx, int sample_rate, int channels, double rate, double pitch, nae_wsola** out)
 {
     if (!ctx) return NAE_ERR_INVALID;
+    (void)nae_use_device(ctx);
     if (!out) return nae_fail(ctx, NAE_ERR_INVALID, "nae_wsola_create: null handle pointer");
     nae_wsola* h = new (std::nothrow) nae_wsola();
     if (!h) return nae_fail(ctx, NAE_ERR_NOMEM, "nae_wsola_create");
@@ -537,6 +539,7 @@ int nae_wsola_create(nae_ctx* ctx, int sample_rate, int channels, double rate, d
 static int wsola_append(nae_wsola* h, const float* p, size_t S, bool host)
 {
     if (!h) return NAE_ERR_INVALID;
+    (void)nae_use_device(h->ctx);
     nae_ctx* ctx = h->ctx;
     if (h->flushed) return nae_fail(ctx, NAE_ERR_STATE, "nae_wsola_put after flush");
     if (S == 0) return NAE_OK;
@@ -564,6 +567,7 @@ int nae_wsola_put_host(nae_wsola* h, const float* interleaved, size_t S) { retur
 int nae_wsola_flush(nae_wsola* h)
 {
     if (!h) return NAE_ERR_INVALID;
+    (void)nae_use_device(h->ctx);
     if (h->flushed) return NAE_OK;
     const StState before = h->st;
     const long long avail = sim_flush(h->cfg, h->st, h->received, nullptr, nullptr);
@@ -585,6 +589,7 @@ size_t nae_wsola_available(const nae_wsola* h)
 static int wsola_take(nae_wsola* h, float* dst, size_t max_frames, size_t* got, bool host)
 {
     if (!h) return NAE_ERR_INVALID;
+    (void)nae_use_device(h->ctx);
     nae_ctx* ctx = h->ctx;
     size_t n = nae_wsola_available(h);
     if (n > max_frames) n = max_frames;
@@ -608,6 +613,7 @@ int nae_wsola_receive_host(nae_wsola* h, float* dst, size_t max_frames, size_t* 
 int nae_wsola_destroy(nae_wsola* h)
 {
     if (!h) return NAE_OK;
+    if (h->ctx) (void)nae_use_device(h->ctx);
     if (h->ctx && h->ctx->stream) (void)hipStreamSynchronize(h->ctx->stream);
     absfifo_free(h->in);
     absfifo_free(h->a);

@@ -1,0 +1,103 @@
+"""CPU: the ONE row of the path that can be pinned against the reference's own code.
+
+`change_volume<T>` (/root/reference/src/processor/audio-vol.cpp:75-100) needs only <algorithm> / <cstdint>, so `make -C oracle ref`
+compiles it from where it lies into oracle/_ref/libref_vol.so (git-ignored; built by __graft_entry__.build() when /root/reference is
+present; the .so travels to the GPU box, the reference does not).  Here: oracle/orc_nodes.c's K1 restatement ≡ that build, bit for
+bit, on the committed golden inputs and outputs, on random frames of the sizes the node sees, and on out-of-range integer products.
+
+Every other loop of the path sits inside a process_payload body between FFmpeg / Boost calls and cannot be compiled without
+stand-ins for headers this image lacks, so K2-K6 stay pinned by the numpy restatement only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libref_vol.so")
+REF_SRC = "/root/reference/src/processor/audio-vol.cpp"
+
+
+@pytest.fixture(scope="module")
+def ref():
+    if not os.path.exists(REF_SO):
+        if not os.path.exists(REF_SRC):
+            pytest.skip("oracle/_ref/libref_vol.so was not built and /root/reference is not on this box")
+        r = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "ref"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+    L = C.CDLL(REF_SO)
+    for n in ("ref_change_volume_f32", "ref_change_volume_s16", "ref_change_volume_s32"):
+        getattr(L, n).argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float]
+        getattr(L, n).restype = None
+    return L
+
+
+def aligned(n, dtype, align=32):
+    """the reference promises its compiler 32-byte aligned destination planes (audio-vol.cpp:95, av_frame_get_buffer(…, 32) at :173)"""
+    raw = np.empty(n * np.dtype(dtype).itemsize + align, np.uint8)
+    off = (-raw.ctypes.data) % align
+    return raw[off:off + n * np.dtype(dtype).itemsize].view(dtype)
+
+
+def ref_change_volume(L, planes, volume):
+    dt = planes[0].dtype
+    fn = {np.dtype(np.float32): L.ref_change_volume_f32, np.dtype(np.int16): L.ref_change_volume_s16, np.dtype(np.int32): L.ref_change_volume_s32}[dt]
+    src = [np.ascontiguousarray(p) for p in planes]
+    dst = [aligned(p.size, dt) for p in src]
+    sp = (C.c_void_p * len(src))(*[p.ctypes.data for p in src])
+    dp = (C.c_void_p * len(dst))(*[p.ctypes.data for p in dst])
+    fn(dp, sp, len(src), src[0].size, C.c_float(volume))
+    return dst
+
+
+def same_bits(a, b):
+    return a.dtype == b.dtype and np.array_equal(a.view(np.uint8), b.view(np.uint8))
+
+
+@pytest.mark.parametrize("key,vols", [("k1_f32", (0.0, 0.70710678, 1.0, 10.0)), ("k1_s16", (0.5, 0.70710678, 1.0, 3.0, 10.0)),
+                                      ("k1_s32", (0.5, 0.70710678, 1.0, 3.0))])
+def test_reference_code_reproduces_the_committed_golden(ref, golden, key, vols):
+    """reference build == numpy golden == oracle on the committed vectors (tests/golden/nodes.npz), out-of-range products included"""
+    g = golden["nodes"]
+    x = g[key + "_in"]
+    for v in vols:
+        r = ref_change_volume(ref, [x], v)[0]
+        o = orc.change_volume([x], v)[0]
+        assert same_bits(r, o), (key, v, "oracle differs from the reference's code")
+        assert same_bits(r, g[f"{key}_v{v}"]), (key, v, "golden differs from the reference's code")
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.int16, np.int32])
+@pytest.mark.parametrize("planes,elems", [(1, 2304), (2, 1152), (1, 8192), (2, 4096), (1, 1), (2, 7), (1, 33)])
+def test_oracle_equals_reference_code_on_random_frames(ref, dtype, planes, elems):
+    rng = np.random.default_rng(elems * 31 + planes)
+    for v in (0.0, 0.25, 0.70710678, 1.0, 1.5, 9.999, 10.0):
+        if dtype == np.float32:
+            src = [rng.uniform(-1.5, 1.5, elems).astype(np.float32) for _ in range(planes)]
+            src[0][:min(elems, 5)] = np.array([0.0, -0.0, 1e-40, np.inf, np.nan], np.float32)[:min(elems, 5)]
+        else:
+            # in range for every volume used here: the reference's float -> int conversion is only defined there
+            lim = int(np.iinfo(dtype).max / 10.5)
+            src = [rng.integers(-lim, lim, elems, dtype=np.int64).astype(dtype) for _ in range(planes)]
+        r = ref_change_volume(ref, src, v)
+        o = orc.change_volume(src, v)
+        for a, b in zip(r, o):
+            assert same_bits(a, b), (dtype, planes, elems, v)
+
+
+@pytest.mark.parametrize("dtype", [np.int16, np.int32])
+def test_out_of_range_integer_products(ref, dtype):
+    """volume * sample beyond the integer type: undefined in C++, `cvttss2si` (0x80000000, then modular narrowing) on the reference's
+    only platform — the behaviour DESIGN.md §5 adopts.  The reference's own code, compiled here at -O3 for x86-64, must agree with
+    the oracle on full-range samples at the node's maximum volume (config.hpp:58: 10) for the pin to cover that choice."""
+    info = np.iinfo(dtype)
+    rng = np.random.default_rng(7)
+    x = rng.integers(info.min, info.max, 4096, dtype=np.int64, endpoint=True).astype(dtype)
+    x[:4] = [info.min, info.max, info.min + 1, info.max - 1]
+    for v in (1.0000001, 2.0, 3.0, 10.0):
+        r = ref_change_volume(ref, [x], v)[0]
+        o = orc.change_volume([x], v)[0]
+        assert same_bits(r, o), (dtype, v, int(np.count_nonzero(r != o)))

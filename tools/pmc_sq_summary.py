@@ -22,7 +22,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # kernel symbol -> the launch label bench.py reports it under
-LABEL = {"pv_pipe_kernel": "pv_synth_kernel", "spectrum_stereo_kernel": "spectrum_kernel"}
+LABEL = {}      # bench.py labels its launches with the names rocprofv3 prints
 WAVES_PER_SIMD = {"pv_pipe_kernel": 8, "spectrum_stereo_kernel": 4, "mix_resample_tile_kernel": 5}
 
 
