@@ -1,9 +1,14 @@
 """CPU: the ONE row of the path that can be pinned against the reference's own code.
 
 `change_volume<T>` (/root/reference/src/processor/audio-vol.cpp:75-100) needs only <algorithm> / <cstdint>, so `make -C oracle ref`
-compiles it from where it lies into oracle/_ref/libref_vol.so (git-ignored; built by __graft_entry__.build() when /root/reference is
-present; the .so travels to the GPU box, the reference does not).  Here: oracle/orc_nodes.c's K1 restatement ≡ that build, bit for
-bit, on the committed golden inputs and outputs, on random frames of the sizes the node sees, and on out-of-range integer products.
+compiles it from where it lies into oracle/_ref/ (git-ignored; built by __graft_entry__.build() when /root/reference is present; the
+.so files travel to the GPU box, the reference does not) — twice: libref_vol.so with g++ (xmake's default toolchain on the
+reference's Linux target) and libref_vol_clang.so with clang.  Here: oracle/orc_nodes.c's K1 restatement ≡ BOTH builds, bit for bit,
+wherever the C++ is defined (every float input; integer products inside the type's range), on the committed golden inputs and
+outputs and on random frames of the sizes the node sees.  Integer products beyond the type's range are undefined behaviour in the
+reference (audio-vol.cpp:98, no clamp): the g++ build wraps like `cvttss2si` + modular narrowing — what the oracle, the goldens and
+the GPU kernel do — while clang's vectorised body SATURATES int16 (`packssdw`) and its scalar tail wraps; the last
+test pins both facts, so "bit-exact int-PCM gain" is a statement about in-range products plus the g++ build's choice beyond them.
 
 Every other loop of the path sits inside a process_payload body between FFmpeg / Boost calls and cannot be compiled without
 stand-ins for headers this image lacks, so K2-K6 stay pinned by the numpy restatement only."""
@@ -17,22 +22,39 @@ import pytest
 import orc
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-REF_SO = os.path.join(ROOT, "oracle", "_ref", "libref_vol.so")
+REF_DIR = os.path.join(ROOT, "oracle", "_ref")
 REF_SRC = "/root/reference/src/processor/audio-vol.cpp"
+BUILDS = {"g++": "libref_vol.so", "clang": "libref_vol_clang.so"}
 
 
-@pytest.fixture(scope="module")
-def ref():
-    if not os.path.exists(REF_SO):
+def load_ref(which):
+    so = os.path.join(REF_DIR, BUILDS[which])
+    if not os.path.exists(so):
         if not os.path.exists(REF_SRC):
-            pytest.skip("oracle/_ref/libref_vol.so was not built and /root/reference is not on this box")
+            pytest.skip("oracle/_ref was not built and /root/reference is not on this box")
         r = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "ref"], capture_output=True, text=True)
         assert r.returncode == 0, r.stdout + r.stderr
-    L = C.CDLL(REF_SO)
+    L = C.CDLL(so)
     for n in ("ref_change_volume_f32", "ref_change_volume_s16", "ref_change_volume_s32"):
         getattr(L, n).argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float]
         getattr(L, n).restype = None
     return L
+
+
+@pytest.fixture(scope="module", params=["g++", "clang"])
+def ref(request):
+    L = load_ref(request.param)
+    L.which = request.param
+    return L
+
+
+def in_range(x, v):
+    """elements whose product the reference's C++ defines: float(x) * v, truncated, representable in x's type"""
+    if x.dtype == np.float32:
+        return np.ones(x.shape, bool)
+    info = np.iinfo(x.dtype)
+    p = np.trunc((x.astype(np.float32) * np.float32(v)).astype(np.float64))
+    return (p >= info.min) & (p <= info.max)
 
 
 def aligned(n, dtype, align=32):
@@ -60,14 +82,17 @@ def same_bits(a, b):
 @pytest.mark.parametrize("key,vols", [("k1_f32", (0.0, 0.70710678, 1.0, 10.0)), ("k1_s16", (0.5, 0.70710678, 1.0, 3.0, 10.0)),
                                       ("k1_s32", (0.5, 0.70710678, 1.0, 3.0))])
 def test_reference_code_reproduces_the_committed_golden(ref, golden, key, vols):
-    """reference build == numpy golden == oracle on the committed vectors (tests/golden/nodes.npz), out-of-range products included"""
+    """reference build == numpy golden == oracle on the committed vectors (tests/golden/nodes.npz); the g++ build also on their
+    out-of-range products (k1_s16 at volume 3 and 10, k1_s32 at 3)"""
     g = golden["nodes"]
     x = g[key + "_in"]
     for v in vols:
         r = ref_change_volume(ref, [x], v)[0]
         o = orc.change_volume([x], v)[0]
-        assert same_bits(r, o), (key, v, "oracle differs from the reference's code")
-        assert same_bits(r, g[f"{key}_v{v}"]), (key, v, "golden differs from the reference's code")
+        m = in_range(x, v) if ref.which == "clang" else np.ones(x.shape, bool)
+        assert m.sum() > 500
+        assert np.array_equal(r[m].view(np.uint8), o[m].view(np.uint8)), (key, v, "oracle differs from the reference's code")
+        assert np.array_equal(r[m].view(np.uint8), g[f"{key}_v{v}"][m].view(np.uint8)), (key, v, "golden differs from the reference's code")
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.int16, np.int32])
@@ -89,15 +114,23 @@ def test_oracle_equals_reference_code_on_random_frames(ref, dtype, planes, elems
 
 
 @pytest.mark.parametrize("dtype", [np.int16, np.int32])
-def test_out_of_range_integer_products(ref, dtype):
-    """volume * sample beyond the integer type: undefined in C++, `cvttss2si` (0x80000000, then modular narrowing) on the reference's
-    only platform — the behaviour DESIGN.md §5 adopts.  The reference's own code, compiled here at -O3 for x86-64, must agree with
-    the oracle on full-range samples at the node's maximum volume (config.hpp:58: 10) for the pin to cover that choice."""
+def test_out_of_range_integer_products(dtype):
+    """volume * sample beyond the integer type (full-range samples up to the node's maximum volume, config.hpp:58: 10) is undefined
+    in the reference's C++.  g++ -O3: `cvttss2si` (0x80000000 on overflow), then modular narrowing — the oracle's choice, bit for bit.
+    clang -O3: the same for int32; for int16 its vector body saturates and its scalar tail wraps, so it agrees with the oracle on
+    in-range products only — which is all the reference defines."""
+    gxx, clang = load_ref("g++"), load_ref("clang")
     info = np.iinfo(dtype)
     rng = np.random.default_rng(7)
-    x = rng.integers(info.min, info.max, 4096, dtype=np.int64, endpoint=True).astype(dtype)
+    x = rng.integers(info.min, info.max, 4099, dtype=np.int64, endpoint=True).astype(dtype)
     x[:4] = [info.min, info.max, info.min + 1, info.max - 1]
     for v in (1.0000001, 2.0, 3.0, 10.0):
-        r = ref_change_volume(ref, [x], v)[0]
         o = orc.change_volume([x], v)[0]
+        r = ref_change_volume(gxx, [x], v)[0]
         assert same_bits(r, o), (dtype, v, int(np.count_nonzero(r != o)))
+        c = ref_change_volume(clang, [x], v)[0]
+        m = in_range(x, v)
+        assert 0 < m.sum() and (v < 2.0 or m.sum() < x.size)
+        assert np.array_equal(c[m], o[m]), (dtype, v)
+        if dtype == np.int16 and v >= 2.0:
+            assert not np.array_equal(c, o)                      # compilers disagree where the reference leaves the result undefined
