@@ -48,7 +48,32 @@ def parse():
     ap.add_argument("--rate", type=float, default=1.0, help="SoundTouch setRate of the pitch node (headline: 1)")
     ap.add_argument("--no-alt", action="store_true", help="skip the side measurement of the SoundTouch-shaped pitch node")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-buffers-on-both-sides measurement (pcie_inclusive)")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the plugin-boundary measurement (host_path)")
     return ap.parse_args()
+
+
+def host_path(seconds=10.0):
+    """The plugin boundary as the editor sees it (include/infra/processor.hpp:108-113): 1152-sample frames through
+    audio_volume_adjust -> audio_amix(2) -> pitch_modifier in the C++ host mirror's fiber runner (one thread, every hop a host frame),
+    one branch and 16 independent branches.  Runs tests/host/selftest (test code: it checks branch 0 against the oracle and times the
+    oracle on the same frames).  Reported beside the headline, never part of `value`."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "host", "selftest")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "nodey-audio-editor_amd", "host"), "-j4"], capture_output=True)
+        subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "host")], capture_output=True)
+    if not os.path.exists(exe):
+        return {"error": "tests/host/selftest is not built"}
+    try:
+        r = subprocess.run([exe, "bench", str(seconds)], capture_output=True, text=True, timeout=240)
+    except subprocess.TimeoutExpired:
+        return {"error": "tests/host/selftest bench timed out"}
+    runs = [json.loads(line[len("HOST_PATH "):]) for line in r.stdout.splitlines() if line.startswith("HOST_PATH ")]
+    if r.returncode != 0 or len(runs) != 2:
+        return {"error": f"selftest bench rc {r.returncode}", "tail": r.stdout[-400:]}
+    return {"what": "C++ host mirror (nodey-audio-editor_amd/host): fiber runner on one thread, per-node contexts, every node batches the frames "
+                    "already waiting behind one wait of its own stream; frames/s = 1152-sample source frames",
+            "one_branch": runs[0], "sixteen_branches": runs[1]}
 
 
 def main():
@@ -288,6 +313,10 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import bench_pcie
         out["pcie_inclusive"] = bench_pcie.measure(nae, device=local_rank, streams=512, chunk=64, S=S, semitones=a.semitones)
+
+    if not a.no_host_path and world == 1:
+        ctx.sync()
+        out["host_path"] = host_path()
 
     # ---- CPU baseline (reported, not the target): the oracle's restatement of the same graph, 1 thread
     if not a.no_cpu_baseline and world == 1:

@@ -13,6 +13,7 @@ namespace nae_fiber
 		std::function<void()> body;
 		std::unique_ptr<char[]> stack;
 		bool done = false;
+		void* local = nullptr;
 	};
 
 	struct Scheduler::Impl
@@ -71,6 +72,13 @@ namespace nae_fiber
 	}
 
 	size_t Scheduler::switches() const { return impl->switches; }
+
+	void*& this_fiber::local()
+	{
+		static thread_local void* thread_slot = nullptr;
+		if (active == nullptr || active->current == nullptr) return thread_slot;
+		return active->current->local;
+	}
 
 	void this_fiber::yield()
 	{

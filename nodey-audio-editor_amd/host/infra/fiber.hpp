@@ -12,6 +12,9 @@ namespace nae_fiber
 	namespace this_fiber
 	{
 		void yield();  // give the other fibers a turn (no-op outside a scheduler)
+		// one pointer of fiber-local storage (boost::fibers::fiber_specific_ptr in the reference's Boost.Fiber); outside a
+		// scheduler: one slot per OS thread
+		void*& local();
 	}
 
 	class Scheduler

@@ -136,6 +136,7 @@ namespace processor
 			Stretch_algorithm algorithm, Batch_stats& batch_stats
 		)
 		{
+			gpu::Node node;  // this node's context (own stream, device by round-robin): first local, destroyed last
 			batch_stats = {};
 			const auto input_item = infra::get_input_item<Audio_stream>(input, "input");
 			const auto output_stream = infra::get_output_item<Audio_stream>(output, "output");

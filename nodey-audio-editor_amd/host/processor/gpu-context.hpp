@@ -1,5 +1,16 @@
 // processor/gpu-context.hpp — how a processor fiber talks to the C ABI without ever blocking the OS thread
 // (all fibers share one thread: /root/reference/src/infra/runner.cpp:65-69).
+//
+// Every RUNNING NODE owns a context (gpu::Node, the first local of its process_payload): its own HIP stream, so
+//   * a node waits for ITS OWN batch — gpu::wait polls the node's stream, not a stream shared with every other node of the graph
+//     (round 3: one process-wide context; a node whose batch had finished kept yielding while any other node's was queued);
+//   * batches of different nodes overlap on the device;
+//   * nodes are spread over the GPUs of the machine: node k of a run goes to device k mod nae_device_count() (the reference runs the
+//     whole graph in ONE process on ONE thread, src/infra/runner.cpp:142-154; every hop between nodes passes host frames anyway —
+//     Audio_stream carries AVFrames — so any node can sit on any device).  $NAE_DEVICE pins all nodes to one device, $NAE_DEVICES
+//     limits the spread to the first n.
+// The node's context is found through one pointer of fiber-local storage (boost::fibers::fiber_specific_ptr in the reference's
+// scheduler), so helpers deep inside a processor need no extra argument.
 #pragma once
 #include "../../../include/nae_gpu.h"
 #include "../infra/fiber.hpp"
@@ -10,23 +21,87 @@
 
 namespace processor::gpu
 {
-	// process-wide context on device $NAE_DEVICE (default 0); Runtime_error if there is no usable GPU —
-	// the adapter has no CPU fallback
+	// what the plugin-boundary benchmark reads (tests/host/selftest.cpp `bench`): waits and polls of all nodes, and how many
+	// nodes had a batch in flight at the same moment
+	struct Flight_stats
+	{
+		size_t waits = 0, polls = 0, nodes = 0;
+		int in_flight = 0, max_in_flight = 0;
+		int devices_used = 0;
+	};
+	inline Flight_stats& flight_stats()
+	{
+		static Flight_stats s;
+		return s;
+	}
+
+	inline int pick_device()
+	{
+		static unsigned next = 0;
+		if (const char* dev = std::getenv("NAE_DEVICE")) return std::atoi(dev);
+		int n = nae_device_count();
+		if (const char* lim = std::getenv("NAE_DEVICES"))
+			if (std::atoi(lim) > 0 && std::atoi(lim) < n) n = std::atoi(lim);
+		if (n <= 0) return 0;  // nae_ctx_create reports the missing device
+		const int d = (int)(next++ % (unsigned)n);
+		if (d + 1 > flight_stats().devices_used) flight_stats().devices_used = d + 1;
+		return d;
+	}
+
+	inline nae_ctx* create_context(int device)
+	{
+		nae_ctx* ctx = nullptr;
+		const int rc = nae_ctx_create(device, &ctx);
+		if (rc != NAE_OK)
+			throw infra::Processor::Runtime_error(
+				"GPU context creation failed",
+				"The MI355X processors need a HIP device; there is no CPU fallback.",
+				infra::fmt("nae_ctx_create(%d) returned %d", device, rc)
+			);
+		return ctx;
+	}
+
+	// the context of one running node; declare it FIRST in process_payload (device buffers and handles die before it)
+	class Node
+	{
+		nae_ctx* ctx_;
+		void* outer;
+
+	  public:
+
+		const int device;
+		bool pending = false;  // a batch of this node is being waited for
+
+		Node() : ctx_(nullptr), outer(nae_fiber::this_fiber::local()), device(pick_device())
+		{
+			ctx_ = create_context(device);
+			nae_fiber::this_fiber::local() = this;
+			flight_stats().nodes++;
+		}
+		Node(const Node&) = delete;
+		Node& operator=(const Node&) = delete;
+		~Node()
+		{
+			nae_fiber::this_fiber::local() = outer;
+			nae_ctx_destroy(ctx_);
+		}
+		nae_ctx* ctx() const { return ctx_; }
+	};
+
+	inline Node* current_node() { return static_cast<Node*>(nae_fiber::this_fiber::local()); }
+
+	// the running node's context; outside a node (unit tests that call a helper directly): one context per process on
+	// device $NAE_DEVICE (default 0)
 	inline nae_ctx* context()
 	{
-		static nae_ctx* ctx = nullptr;
-		if (ctx == nullptr)
+		if (Node* node = current_node()) return node->ctx();
+		static nae_ctx* fallback = nullptr;
+		if (fallback == nullptr)
 		{
 			const char* dev = std::getenv("NAE_DEVICE");
-			const int rc = nae_ctx_create(dev ? std::atoi(dev) : 0, &ctx);
-			if (rc != NAE_OK)
-				throw infra::Processor::Runtime_error(
-					"GPU context creation failed",
-					"The MI355X processors need a HIP device; there is no CPU fallback.",
-					infra::fmt("nae_ctx_create returned %d", rc)
-				);
+			fallback = create_context(dev ? std::atoi(dev) : 0);
 		}
-		return ctx;
+		return fallback;
 	}
 
 	// non-zero status -> the reference's user-facing error type (include/infra/processor.hpp:64-77)
@@ -40,37 +115,52 @@ namespace processor::gpu
 		);
 	}
 
-	// poll-and-yield until the context's stream is idle (or stop is requested)
+	// poll-and-yield until everything THIS NODE has queued is done (or stop is requested)
 	inline void wait(const std::atomic<bool>& stop_token)
 	{
+		nae_ctx* ctx = context();
+		Node* node = current_node();
+		Flight_stats& fs = flight_stats();
+		fs.waits++;
 		for (;;)
 		{
-			const int r = nae_poll(context());
-			if (r == 1) return;
-			if (r < 0) check(r, "nae_poll");
-			if (stop_token) { nae_sync(context()); return; }
+			const int r = nae_poll(ctx);
+			fs.polls++;
+			if (r != 0 || stop_token)
+			{
+				if (node && node->pending) { node->pending = false; fs.in_flight--; }
+				if (r < 0) check(r, "nae_poll");
+				if (r == 0) nae_sync(ctx);
+				return;
+			}
+			if (node && !node->pending)
+			{
+				node->pending = true;
+				if (++fs.in_flight > fs.max_in_flight) fs.max_in_flight = fs.in_flight;
+			}
 			nae_fiber::this_fiber::yield();
 		}
 	}
 
-	// grow-only device scratch
+	// grow-only device scratch of the node that created it
 	class Device_buffer
 	{
+		nae_ctx* ctx;
 		void* ptr = nullptr;
 		size_t bytes = 0;
 
 	  public:
 
-		Device_buffer() = default;
+		Device_buffer() : ctx(context()) {}
 		Device_buffer(const Device_buffer&) = delete;
 		Device_buffer& operator=(const Device_buffer&) = delete;
-		~Device_buffer() { if (ptr) nae_free(context(), ptr); }
+		~Device_buffer() { if (ptr) { nae_sync(ctx); nae_free(ctx, ptr); } }
 		void* reserve(size_t want)
 		{
 			if (want > bytes)
 			{
-				if (ptr) { nae_sync(context()); nae_free(context(), ptr); ptr = nullptr; }
-				check(nae_malloc(context(), want + want / 2 + 256, &ptr), "nae_malloc");
+				if (ptr) { nae_sync(ctx); nae_free(ctx, ptr); ptr = nullptr; }
+				check(nae_malloc(ctx, want + want / 2 + 256, &ptr), "nae_malloc");
 				bytes = want + want / 2 + 256;
 			}
 			return ptr;

@@ -78,6 +78,9 @@ class Test_sink : public infra::Processor
 
 	std::vector<std::shared_ptr<const Audio_frame>> frames;
 	size_t max_fill = 0;
+	bool lazy_consumer = true;   // pops on every 4th turn only: forces back-pressure (the tests); false: the benchmark's sink
+	bool keep = true;            // false: count the frames, drop the samples
+	size_t n_frames = 0, n_samples = 0;
 
 	static Info get_processor_info() { return {"test_sink", "Test Sink", false, [] { return std::unique_ptr<Processor>(new Test_sink); }, ""}; }
 	Info get_processor_info_non_static() const override { return get_processor_info(); }
@@ -98,7 +101,7 @@ class Test_sink : public infra::Processor
 		while (!stop_token)
 		{
 			max_fill = std::max(max_fill, s.buffered_count());
-			if ((++lazy & 3) != 0) { nae_fiber::this_fiber::yield(); continue; }  // a slow consumer: forces back-pressure
+			if (lazy_consumer && (++lazy & 3) != 0) { nae_fiber::this_fiber::yield(); continue; }  // a slow consumer: forces back-pressure
 			auto r = s.try_pop();
 			if (!r.has_value())
 			{
@@ -106,7 +109,9 @@ class Test_sink : public infra::Processor
 				nae_fiber::this_fiber::yield();
 				continue;
 			}
-			frames.push_back(r.value());
+			n_frames++;
+			n_samples += (size_t)r.value()->data()->nb_samples;
+			if (keep) frames.push_back(r.value());
 		}
 	}
 	std::vector<float> interleaved() const  // FLT frames concatenated
@@ -635,9 +640,121 @@ static void test_gpu_bimix_v1()
 		  "bimix batches the waiting frames: " << mix->batch_stats.rounds << " rounds behind " << mix->batch_stats.waits << " waits");
 }
 
+// ------------------------------------------------------------------------------------------------ plugin-boundary benchmark
+// What the editor sees (include/infra/processor.hpp:108-113: process_payload; the loop it runs, src/processor/audio-vol.cpp:137-150):
+// 1152-sample frames of 48 kHz stereo f32 pushed through  audio_volume_adjust -> audio_amix(2) -> pitch_modifier  by the fiber
+// runner on ONE thread, every hop a host frame (upload, kernels, download).  `branches` independent copies of that graph share the
+// runner, as independent tracks of a project would.  Prints one line:  HOST_PATH {json}
+#include <chrono>
+static void bench_host_path(int branches, double seconds, bool print)
+{
+	const int S = (int)(seconds * 48000);
+	const float semis = 3.0f, vol = 0.7071f;
+	Runner r;
+	std::vector<std::shared_ptr<Test_source>> srcs;
+	std::vector<std::shared_ptr<Test_sink>> sinks;
+	int id = 1;
+	for (int b = 0; b < branches; b++)
+	{
+		auto a = std::make_shared<Test_source>(), c = std::make_shared<Test_source>();
+		a->samples = uniform((size_t)S * 2, 100 + 2 * b);
+		c->samples = uniform((size_t)S * 2, 101 + 2 * b);
+		auto gain = std::make_shared<Audio_vol>();
+		gain->set_volume(vol);
+		auto mix = std::make_shared<Audio_amix>();
+		Json::Value v;
+		v["input_num"] = 2;
+		v["volumes0"] = 0.5; v["locks0"] = false;
+		v["volumes1"] = 0.5; v["locks1"] = false;
+		mix->deserialize(v);
+		auto pitch = std::make_shared<Pitch_modifier>();
+		Json::Value pv;
+		pv["pitch"] = (double)semis;
+		pitch->deserialize(pv);
+		auto sink = std::make_shared<Test_sink>();
+		sink->lazy_consumer = false;
+		sink->keep = b == 0;
+		const int n_a = id++, n_c = id++, n_g = id++, n_m = id++, n_p = id++, n_s = id++;
+		r.add_node(n_a, a); r.add_node(n_c, c); r.add_node(n_g, gain); r.add_node(n_m, mix); r.add_node(n_p, pitch); r.add_node(n_s, sink);
+		r.add_link({n_a, "output", n_g, "input"});
+		r.add_link({n_g, "output", n_m, "input_1"});
+		r.add_link({n_c, "output", n_m, "input_2"});
+		r.add_link({n_m, "output", n_p, "input"});
+		r.add_link({n_p, "output", n_s, "input"});
+		srcs.push_back(a); srcs.push_back(c);
+		sinks.push_back(sink);
+	}
+	gpu::flight_stats() = gpu::Flight_stats{};
+	const auto t0 = std::chrono::steady_clock::now();
+	const bool ok = r.run();
+	const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	CHECK(ok, "host-path benchmark graph runs");
+	if (!ok)
+	{
+		for (auto& [nid, res] : r.get_processor_resources())
+			if (!res->error_text.empty()) std::cout << "  node " << nid << ": " << res->error_text << "\n";
+		return;
+	}
+	const gpu::Flight_stats fs = gpu::flight_stats();
+	size_t out_samples = 0;
+	for (auto& s : sinks) out_samples += s->n_samples;
+	CHECK(out_samples >= (size_t)branches * (size_t)(S - 2), "every branch delivered its audio (" << out_samples << " sample-frames)");
+	// the CPU oracle on the same frames, one thread (the reference runs the graph on one thread: src/infra/runner.cpp:65-69)
+	double cpu = 0.0;
+	double err = 0.0;
+	{
+		const auto c0 = std::chrono::steady_clock::now();
+		std::vector<float> g((size_t)S * 2), gL(S), gR(S), cL(S), cR(S), oL(S), oR(S), m((size_t)S * 2), ref((size_t)S * 2);
+		for (int b = 0; b < branches; b++)
+		{
+			const float* sp[1] = {srcs[2 * b]->samples.data()};
+			float* dp[1] = {g.data()};
+			orc_change_volume_f32(dp, sp, 1, S * 2, vol);
+			const std::vector<float>& c = srcs[2 * b + 1]->samples;
+			for (int i = 0; i < S; i++) { gL[i] = g[2 * i]; gR[i] = g[2 * i + 1]; cL[i] = c[2 * i]; cR[i] = c[2 * i + 1]; }
+			const float* inL[2] = {gL.data(), cL.data()};
+			const float* inR[2] = {gR.data(), cR.data()};
+			const float w[2] = {0.5f, 0.5f};
+			orc_amix_f32(inL, inR, w, 2, oL.data(), oR.data(), S);
+			for (int i = 0; i < S; i++) { m[2 * i] = oL[i]; m[2 * i + 1] = oR[i]; }
+			orc_stretch_f32(m.data(), S, 2, 1.0, (double)std::pow(2.0f, semis / 12.0f), ref.data());
+			if (b == 0)
+			{
+				auto got = sinks[0]->interleaved();
+				got.resize(ref.size());       // (the mixer's flush frames append silence behind the signal)
+				err = rel_rms(got, ref);
+			}
+		}
+		cpu = std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count();
+	}
+	CHECK(err <= 1e-4, "branch 0 of the benchmark graph within 1e-4 RMS of the oracle: " << err);
+	if (!print) return;
+	const double in_frames = (double)branches * 2.0 * ((S + 1151) / 1152);      // 1152-sample frames the sources pushed
+	char line[1024];
+	std::snprintf(line, sizeof line,
+				  "HOST_PATH {\"graph\": \"audio_volume_adjust -> audio_amix(2) -> pitch_modifier(+3 st), 48 kHz stereo f32, 1152-sample frames\", "
+				  "\"branches\": %d, \"seconds_per_branch\": %.1f, \"wall_s\": %.4f, \"source_frames_per_s\": %.1f, \"sample_frames_per_s\": %.1f, "
+				  "\"real_time_factor\": %.1f, \"gpu_nodes\": %zu, \"devices_used\": %d, \"waits\": %zu, \"waits_per_source_frame\": %.4f, "
+				  "\"polls_per_wait\": %.2f, \"max_nodes_in_flight\": %d, \"fiber_switches\": %zu, \"cpu_oracle_s\": %.4f, "
+				  "\"cpu_oracle_sample_frames_per_s\": %.1f, \"rel_rms_branch0\": %.3g}",
+				  branches, seconds, wall, in_frames / wall, (double)branches * S / wall, (double)branches * seconds / wall, fs.nodes, fs.devices_used,
+				  fs.waits, fs.waits / in_frames, fs.waits ? (double)fs.polls / fs.waits : 0.0, fs.max_in_flight, r.context_switches(), cpu,
+				  (double)branches * S / cpu, err);
+	std::cout << line << "\n";
+}
+
 int main(int argc, char** argv)
 {
 	const std::string mode = argc > 1 ? argv[1] : "cpu";
+	if (mode == "bench")
+	{
+		const double seconds = argc > 2 ? std::atof(argv[2]) : 20.0;
+		bench_host_path(1, 2.0, false);     // untimed: module load, first-launch costs
+		bench_host_path(1, seconds, true);
+		bench_host_path(16, seconds, true);
+		std::cout << (failures ? "SELFTEST FAILED " : "SELFTEST OK ") << mode << " failures=" << failures << "\n";
+		return failures ? 1 : 0;
+	}
 	test_streams_and_scheduler();
 	test_registry_and_json();
 	test_bimix_align_step();

@@ -1,6 +1,6 @@
 #!/bin/bash
 # quick kernel timing on the GPU box: per-kernel avg ms of the bench workload
-python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pcie "$@" | python -c "
+python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pcie --no-host-path "$@" | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 print('value %.4g sf/s  ms/step %.2f' % (d['value'], d['ms_per_step']))

@@ -1,7 +1,7 @@
 #!/bin/bash
 # the C5 graph at other pitch-node settings than the headline's (+3 semitones): step time and the top kernels
 for args in "--semitones 3" "--semitones -3" "--semitones 7" "--semitones -7" "--rate 1.5 --semitones -7.01955" "--rate 0.8 --semitones 0" "--semitones 0"; do
-  python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pcie $args | python -c "
+  python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pcie --no-host-path $args | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 w=d.get('pitch_node_soundtouch_algorithm',{})

@@ -7,7 +7,7 @@ OUT=$1; shift
 R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $R/$OUT
 cd /tmp; export TMPDIR=/tmp
-BENCH="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pcie --no-kernel-timing"
+BENCH="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pcie --no-host-path --no-kernel-timing"
 i=0
 for grp in FETCH_SIZE WRITE_SIZE; do
   i=$((i+1))
