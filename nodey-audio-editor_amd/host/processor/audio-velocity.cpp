@@ -220,7 +220,10 @@ namespace processor
 							time_seconds = frame->pts * av_q2d(frame->time_base);
 							sample_rate = frame->sample_rate;
 						}
-						while (!stop_token && soundtouch.available() > max_queued_samples) nae_fiber::this_fiber::yield();
+						// (:399-400 waits while more than 65536 samples are queued in SoundTouch.  Only this fiber takes samples out, and a
+						// batched put adds up to 16 frames at once, so instead of waiting the loop below receives until the queue is
+						// under one chunk again: the queue never grows beyond one batch.)
+						static_assert(max_queued_samples >= 16 * 1152 * 3, "a batch fits the reference's queue bound");
 						size_t total = 0;
 						float* samples = upload_as_f32(batch, d_raw, d_f32, &total);
 						soundtouch.put(samples, total);
@@ -235,7 +238,12 @@ namespace processor
 					const uint32_t min_samples = time_ratio * 1152;
 					const uint32_t max_samples = time_ratio * 1152 * 3;
 					if (soundtouch.available() > min_samples)
-						acquire_func((int)std::min<size_t>(soundtouch.available(), max_samples));
+					{
+						// the reference receives one chunk per loop turn because it puts one frame per turn (:403,416-424); a batched put
+						// makes several chunks available, and all of them are taken now (chunk sizes stay inside [min, max])
+						while (!stop_token && soundtouch.available() > min_samples)
+							acquire_func((int)std::min<size_t>(soundtouch.available(), max_samples));
+					}
 					else if (input_stream_eof)
 					{
 						soundtouch.flush();

@@ -53,6 +53,7 @@ namespace processor
 
 		nae_ctx* ctx = gpu::context();
 		gpu::Device_buffer d_src, d_dst;
+		batch_stats = {};
 
 		// Batching: one launch per frame is launch-bound (a 1152-sample frame is 9 KB), so every
 		// frame that is ALREADY waiting in the input stream (at most its capacity, 16) joins the batch as long as it
@@ -146,6 +147,8 @@ namespace processor
 				for (int p = 0; p < slot.planes; p++)
 					gpu::check(nae_memcpy_d2h(ctx, slot.dst->data()->data[p], d + slot.offset[p], slot.plane_bytes), "d2h");
 			gpu::wait(stop_token);
+			batch_stats.rounds += batch.size();
+			batch_stats.waits++;
 			for (const Slot& slot : batch) push_frame(slot.dst);
 		}
 		for (auto& channel : output_item) channel->set_eof();  // audio-vol.cpp:249

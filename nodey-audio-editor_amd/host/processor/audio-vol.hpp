@@ -11,6 +11,8 @@ namespace processor
 
 	  public:
 
+		Batch_stats batch_stats;  // of the last process_payload: frames scaled / waits (one launch and one wait per batch)
+
 		static infra::Processor::Info get_processor_info();
 		Processor::Info get_processor_info_non_static() const override { return get_processor_info(); }
 		std::vector<infra::Processor::Pin_attribute> get_pin_attributes() const override;

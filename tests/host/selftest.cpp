@@ -245,26 +245,14 @@ static void test_gpu_volume()
 		r.add_node(3, sink);
 		r.add_link({1, "output", 2, "input"});
 		r.add_link({2, "output", 3, "input"});
-		nae_ctx* gctx = processor::gpu::context();
-		nae_prof_reset(gctx);
-		nae_prof_enable(gctx, 1);
 		const bool ok = r.run();
-		nae_prof_enable(gctx, 0);
 		CHECK(ok, "volume graph runs (format " << format << "): " << r.get_processor_resources().at(2)->error_text);
 		if (!ok) continue;
 		CHECK(sink->frames.size() == (20000 + 1151) / 1152, "frame count preserved");
 		{
-			// batching: frames already queued behind the first share its launch
-			uint64_t launches = 0;
-			const int n = nae_prof_get(gctx, -1, nullptr, 0, nullptr, nullptr);
-			for (int k = 0; k < n; k++)
-			{
-				char name[128];
-				double ms = 0;
-				uint64_t cnt = 0;
-				nae_prof_get(gctx, k, name, sizeof name, &ms, &cnt);
-				launches += cnt;
-			}
+			// batching: frames already queued behind the first share its launch and its wait
+			const size_t launches = vol->batch_stats.waits;
+			CHECK(vol->batch_stats.rounds == sink->frames.size(), "every frame went through a batch");
 			CHECK(launches >= 1 && launches < sink->frames.size(), "volume node batches queued frames: " << launches << " launches for " << sink->frames.size() << " frames");
 		}
 		size_t pos = 0;
@@ -646,6 +634,7 @@ static void test_gpu_bimix_v1()
 // runner on ONE thread, every hop a host frame (upload, kernels, download).  `branches` independent copies of that graph share the
 // runner, as independent tracks of a project would.  Prints one line:  HOST_PATH {json}
 #include <chrono>
+#include <thread>
 static void bench_host_path(int branches, double seconds, bool print)
 {
 	const int S = (int)(seconds * 48000);
@@ -685,10 +674,24 @@ static void bench_host_path(int branches, double seconds, bool print)
 		sinks.push_back(sink);
 	}
 	gpu::flight_stats() = gpu::Flight_stats{};
+	// watchdog: a graph that has not finished after 60 s is stopped and the nodes still running are named (never hang the box)
+	std::atomic<bool> finished{false};
+	std::string stuck;
+	std::thread watchdog([&] {
+		for (int i = 0; i < 600 && !finished; i++) std::this_thread::sleep_for(std::chrono::milliseconds(100));
+		if (finished) return;
+		for (auto& [nid, res] : r.get_processor_resources())
+			if (res->state == Runner::State::Running) stuck += " " + std::to_string(nid) + ":" + res->processor->get_processor_info_non_static().identifier;
+		r.request_stop();
+	});
 	const auto t0 = std::chrono::steady_clock::now();
 	const bool ok = r.run();
 	const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	finished = true;
+	watchdog.join();
+	CHECK(stuck.empty(), "host-path benchmark graph finished by itself; still running after 60 s:" << stuck);
 	CHECK(ok, "host-path benchmark graph runs");
+	if (!stuck.empty()) { std::cout << std::flush; return; }
 	if (!ok)
 	{
 		for (auto& [nid, res] : r.get_processor_resources())
@@ -717,12 +720,31 @@ static void bench_host_path(int branches, double seconds, bool print)
 			const float w[2] = {0.5f, 0.5f};
 			orc_amix_f32(inL, inR, w, 2, oL.data(), oR.data(), S);
 			for (int i = 0; i < S; i++) { m[2 * i] = oL[i]; m[2 * i + 1] = oR[i]; }
-			orc_stretch_f32(m.data(), S, 2, 1.0, (double)std::pow(2.0f, semis / 12.0f), ref.data());
+			// the mixer ends its stream with flush frames of silence (audio-amix.cpp:281-292,320): the pitch node sees Sp >= S frames
+			const size_t Sp = b == 0 ? std::max<size_t>(sinks[0]->n_samples, (size_t)S) : (size_t)S;
+			m.resize(Sp * 2, 0.0f);
+			ref.resize(Sp * 2);
+			orc_stretch_f32(m.data(), Sp, 2, 1.0, (double)std::pow(2.0f, semis / 12.0f), ref.data());
 			if (b == 0)
 			{
 				auto got = sinks[0]->interleaved();
-				got.resize(ref.size());       // (the mixer's flush frames append silence behind the signal)
+				const size_t got_len = got.size();
+				CHECK(got.size() == ref.size(), "pitch node delivers the length its input has: " << got.size() / 2 << " vs " << ref.size() / 2);
+				got.resize(ref.size());
 				err = rel_rms(got, ref);
+				if (err > 1e-6)
+				{
+					size_t first = ref.size(), last = 0, worst = 0;
+					for (size_t i = 0; i < ref.size(); i++)
+						if (std::fabs(got[i] - ref[i]) > 1e-4f)
+						{
+							if (first == ref.size()) first = i;
+							last = i;
+							if (std::fabs(got[i] - ref[i]) > std::fabs(got[worst] - ref[worst])) worst = i;
+						}
+					std::cout << "  branch 0: " << got_len / 2 << " frames delivered for " << ref.size() / 2 << "; |diff| > 1e-4 from sample-frame " << first / 2
+							  << " to " << last / 2 << ", worst " << std::fabs(got[worst] - ref[worst]) << " at " << worst / 2 << "\n";
+				}
 			}
 		}
 		cpu = std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count();
