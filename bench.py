@@ -27,7 +27,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.
 SEMITONES = 3.0
 BINS = 513
 # issue interval of an add/sub/mul/fma mix, cycles per wave-instruction per SIMD, by waves resident per SIMD (s_memtime,
-# tools/ubench/valu_issue.hip -> profiles/r02_valu_issue.md, row "add/sub/mul/fma mix of a radix-8 butterfly")
+# tools/ubench/valu_issue.hip -> profiles/r02_valu_issue.md, row "add/sub/mul/fma mix of a radix-8 butterfly").  The 5-wave entry is
+# INTERPOLATED between the measured 4- and 6-wave rows (the micro-benchmark has no 5-wave row).
 VALU_MIX_CYCLES_PER_INSTR = {1: 5.44, 2: 2.72, 3: 1.82, 4: 1.94, 5: 1.8, 6: 1.65, 8: 1.26}
 
 

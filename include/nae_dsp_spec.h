@@ -30,7 +30,8 @@
  *   sign bit of re: i = 0x80000000 - i          (1/2 turn - angle;  wraps: +1/2 and -1/2 turn are the same phase)
  *   sign bit of im: i = -i
  * The octants follow the SIGN BITS (atan2(+0, -0) is half a turn, as in C); a vanishing bin (mx < 2^-100) has t = 0; a bin
- * whose |re| + |im| is not finite (NaN, Inf, or the sum overflows) has phase 0.  Accurate for 2^-100 <= mx <= 2^100.           */
+ * with |re| + |im| not below NAE_ATAN_HUGE = 2^100 — which includes NaN, Inf and a sum that overflows — has phase 0 (beyond
+ * 1.6e38 the integer seed would wrap; the cut sits where the accuracy guarantee ends).  Accurate for 2^-100 <= mx < 2^100.    */
 #define NAE_ATAN_C0 1.591543257e-01f
 #define NAE_ATAN_C1 -5.302623659e-02f
 #define NAE_ATAN_C2 3.152511641e-02f
@@ -40,6 +41,7 @@
 #define NAE_ATAN_C6 1.084129326e-03f
 #define NAE_ATAN_SCALE 4294967296.0f   /* 2^32: multiplying a coefficient by it is exact */
 #define NAE_ATAN_TINY 7.888609052e-31f /* 2^-100 */
+#define NAE_ATAN_HUGE 1.267650600e+30f /* 2^100  */
 #define NAE_RCP_MAGIC 0x7EF311C7u      /* integer seed of 1/x: relative error < 0.13, three Newton steps -> < 1e-7 */
 
 /* 1/sqrt(2) rounded to f32, used by the 8-point butterflies */

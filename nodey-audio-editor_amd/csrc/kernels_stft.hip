@@ -360,21 +360,27 @@ constexpr int kRsMaxSpan = 4096 + 32;            // staged source samples per ch
 // coefficient table -> LDS (rows rotated by rs_slot): 16-byte loads, ALL of a thread's loads requested before the first LDS write.
 // (The table is 8 KB per workgroup out of L2; one dword per thread and trip with a wait in every trip — what the first version
 // did — put eight serial L2 round trips in front of every workgroup's staging loads.)
+// Assumes (checked where it can be): workgroups of kRsThreads threads (every caller's __launch_bounds__), a 16-byte aligned
+// table (hipMalloc), rows of a whole number of float4.
+constexpr int kRsThreads = 256;
+constexpr int kRsRowQuads = NAE_RS_TAPS / 4;                                 // float4 per coefficient row
+static_assert(NAE_RS_TAPS % 4 == 0 && (kRsRowQuads & (kRsRowQuads - 1)) == 0, "a coefficient row is a power-of-two number of float4");
+static_assert(kRsRow % 4 == 0 && kRsRow >= NAE_RS_TAPS, "LDS rows keep 16-byte alignment and hold a whole row");
 __device__ __forceinline__ void rs_fill_table(float* stab, const float* __restrict__ tab, int rot)
 {
-    constexpr int kQuads = (NAE_RS_PHASES + 1) * (NAE_RS_TAPS / 4);          // 516 float4
-    constexpr int kTrips = (kQuads + 255) / 256;
+    constexpr int kQuads = (NAE_RS_PHASES + 1) * kRsRowQuads;                // 516 float4
+    constexpr int kTrips = (kQuads + kRsThreads - 1) / kRsThreads;
     const float4* t4 = reinterpret_cast<const float4*>(tab);
     float4 v[kTrips];
 #pragma unroll
     for (int u = 0; u < kTrips; u++) {
-        const int i = threadIdx.x + 256 * u;
+        const int i = threadIdx.x + kRsThreads * u;
         v[u] = i < kQuads ? t4[i] : float4{0.0f, 0.0f, 0.0f, 0.0f};
     }
 #pragma unroll
     for (int u = 0; u < kTrips; u++) {
-        const int i = threadIdx.x + 256 * u;
-        if (i < kQuads) *reinterpret_cast<float4*>(stab + rs_slot(i >> 2, rot) * kRsRow + 4 * (i & 3)) = v[u];
+        const int i = threadIdx.x + kRsThreads * u;
+        if (i < kQuads) *reinterpret_cast<float4*>(stab + rs_slot(i / kRsRowQuads, rot) * kRsRow + 4 * (i % kRsRowQuads)) = v[u];
     }
 }
 
@@ -471,7 +477,7 @@ __device__ __forceinline__ void rs_apply_stereo(const float* stab, const float* 
 }
 
 template <bool kStereo, int NS>
-__global__ __launch_bounds__(256) void resample_tile_kernel(SigViewD src, RsParams p, const float* __restrict__ tab,
+__global__ __launch_bounds__(kRsThreads) void resample_tile_kernel(SigViewD src, RsParams p, const float* __restrict__ tab,
                                                            OutViewD out, int span_alloc, long long n_streams)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char rs_smem[];
@@ -578,7 +584,7 @@ struct MixFuseD {
 };
 
 template <int NS>
-__global__ __launch_bounds__(256) void mix_resample_tile_kernel(MixFuseD f, RsParams p, const float* __restrict__ tab, OutViewD out,
+__global__ __launch_bounds__(kRsThreads) void mix_resample_tile_kernel(MixFuseD f, RsParams p, const float* __restrict__ tab, OutViewD out,
                                                                int span_alloc, long long n_streams)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char rs_smem[];

@@ -467,7 +467,8 @@ constexpr int kAaTileFused = kAaTile - 3;
 // cu.pos / cu.fr [jt + u], evaluated from the raw signal while staging (cu.n_limit = number of cubic outputs that
 // exist; beyond it the filter reads zeros); the transposed signal never touches HBM.
 // (__launch_bounds__(256, 8): left to itself the compiler spent 85 VGPRs — 5 waves per SIMD — on a body that needs 49; at 8 waves
-// per SIMD the vector unit issues an instruction per 1.26 instead of 1.8 cycles: 4.58 -> 3.95 ms at C5)
+// per SIMD the vector unit issues an instruction per 1.26 cycles (measured, profiles/r02_valu_issue.md) instead of ~1.8 (interpolated
+// between the measured 4- and 6-wave rows): 4.58 -> 3.95 ms at C5)
 template <int CH, bool kCubic, bool kCubicIn = false>
 __global__ __launch_bounds__(256, 8) void st_aa_kernel(DView in, AaParams p, DOut out, CuFuse cu)
 {

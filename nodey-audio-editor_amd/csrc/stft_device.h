@@ -268,111 +268,9 @@ __device__ __forceinline__ void fft512_pad_bc_g(cf (&v)[8], const FftLds& L, con
     dft8_fwd(v);
 }
 
-// transposes, passes B and C; behind the reads of the second transpose it requests 8 more values (extra[r] = xp[64 r]: the
-// synthesis window of the vocoder), whose round trip then hides behind pass C
-__device__ __forceinline__ void fft512_pad_bc_x(cf (&v)[8], const FftLds& L, const cf* xp, cf (&extra)[8])
-{
-#pragma unroll
-    for (int q = 0; q < 8; q++) lds_st(L.nat + 72 * q, v[q]);
-    wave_lds_sync();
-#pragma unroll
-    for (int j = 0; j < 8; j++) v[j] = lds_ld(L.t1r + 8 * j);
-    wave_lds_sync();
-    {
-        cf w[7];
-#pragma unroll
-        for (int p = 1; p < 8; p++) w[p - 1] = lds_ld(L.twb + p);
-        dft8_fwd(v);
-#pragma unroll
-        for (int p = 1; p < 8; p++) v[p] = cmul_tw(v[p], w[p - 1]);
-    }
-#pragma unroll
-    for (int p = 0; p < 8; p++) lds_st(L.t2w + 8 * p, v[p]);
-    wave_lds_sync();
-#pragma unroll
-    for (int j = 0; j < 8; j++) v[j] = lds_ld(L.nat + 66 * j);
-#pragma unroll
-    for (int r = 0; r < 8; r++) extra[r] = lds_ld(xp + 64 * r);
-    wave_lds_sync();
-    dft8_fwd(v);
-}
-
-// Transpose 1 without LDS.  T1 exchanges the register index q with lane bits [5:3] (lane (m, qq) register j <- lane (m, j)
-// register qq), i.e. three butterfly stages with partners lane ^ 32, ^ 16, ^ 8:
-//   ^ 32, ^ 16: v_permlane32_swap / v_permlane16_swap exchange the upper half (odd rows) of one register with the lower half
-//               (even rows) of another in ONE instruction — exactly the butterfly of a register pair;
-//   ^ 8:        row_ror:8 DPP moves (a rotation by 8 inside a 16-lane row is lane ^ 8) with a bank mask selecting which half-row
-//               is written: 3 moves per register pair.
-// 40 vector instructions replace 8 ds_write_b64 + 8 ds_read_b64.  In a throughput-bound FFT loop that is a wash
-// (profiles/r02_fftpad.md: 147 against 141 cycles per FFT per CU at 8 waves per SIMD); in the vocoder pipeline the vector unit
-// idles more than half of the time while every LDS round trip costs the wave several hundred cycles of queueing behind the
-// other 31 waves' bursts (profiles/r03_pipe_stamps*.txt) — there it removes one round trip per FFT from the step's critical
-// path and a third of the LDS writes.
-__device__ __forceinline__ void xlane_swap32(float& lo_keeps, float& hi_keeps)
-{
-    // afterwards: lanes 0-31 of `hi_keeps` hold what lanes 32-63 of `lo_keeps` held, and vice versa
-    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo_keeps), __float_as_uint(hi_keeps), false, false);
-    lo_keeps = __uint_as_float(r.x);
-    hi_keeps = __uint_as_float(r.y);
-}
-__device__ __forceinline__ void xlane_swap16(float& lo_keeps, float& hi_keeps)
-{
-    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    const u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(lo_keeps), __float_as_uint(hi_keeps), false, false);
-    lo_keeps = __uint_as_float(r.x);
-    hi_keeps = __uint_as_float(r.y);
-}
-__device__ __forceinline__ void xlane_swap8(float& lo_keeps, float& hi_keeps)
-{
-    // lanes with bit 3 clear: hi_keeps <- partner's lo_keeps;  lanes with bit 3 set: lo_keeps <- partner's hi_keeps
-    const unsigned a = __float_as_uint(lo_keeps), b = __float_as_uint(hi_keeps);
-    const unsigned t = __builtin_amdgcn_update_dpp(0u, b, 0x128, 0xf, 0xf, false);        // b of lane ^ 8
-    const unsigned b2 = __builtin_amdgcn_update_dpp(b, a, 0x128, 0xf, 0x3, false);       // banks 0,1 (bit 3 clear) <- a of lane ^ 8
-    const unsigned a2 = __builtin_amdgcn_update_dpp(a, t, 0xE4, 0xf, 0xC, false);        // banks 2,3 (bit 3 set) <- t
-    lo_keeps = __uint_as_float(a2);
-    hi_keeps = __uint_as_float(b2);
-}
-__device__ __forceinline__ void t1_xlane(cf (&v)[8])
-{
-    // register bit 2 <-> lane bit 5
-#pragma unroll
-    for (int r = 0; r < 4; r++) { xlane_swap32(v[r].x, v[r + 4].x); xlane_swap32(v[r].y, v[r + 4].y); }
-    // register bit 1 <-> lane bit 4
-#pragma unroll
-    for (int r = 0; r < 8; r++)
-        if (!(r & 2)) { xlane_swap16(v[r].x, v[r + 2].x); xlane_swap16(v[r].y, v[r + 2].y); }
-    // register bit 0 <-> lane bit 3
-#pragma unroll
-    for (int r = 0; r < 8; r += 2) { xlane_swap8(v[r].x, v[r + 1].x); xlane_swap8(v[r].y, v[r + 1].y); }
-}
-
-// passes B and C with transpose 1 across lanes and transpose 2 through LDS.  The pass-B twiddles are requested first (their
-// round trip hides behind the cross-lane moves); kExtra: 8 more values (extra[r] = xp[64 r]) are requested behind the reads of
-// transpose 2 and arrive behind pass C
-template <bool kExtra>
-__device__ __forceinline__ void fft512_xbc(cf (&v)[8], const FftLds& L, const cf* xp, cf (&extra)[8])
-{
-    cf w[7];
-#pragma unroll
-    for (int p = 1; p < 8; p++) w[p - 1] = lds_ld(L.twb + p);
-    t1_xlane(v);
-    dft8_fwd(v);
-#pragma unroll
-    for (int p = 1; p < 8; p++) v[p] = cmul_tw(v[p], w[p - 1]);
-#pragma unroll
-    for (int p = 0; p < 8; p++) lds_st(L.t2w + 8 * p, v[p]);
-    wave_lds_sync();
-#pragma unroll
-    for (int j = 0; j < 8; j++) v[j] = lds_ld(L.nat + 66 * j);
-    if (kExtra) {
-#pragma unroll
-        for (int r = 0; r < 8; r++) extra[r] = lds_ld(xp + 64 * r);
-    }
-    wave_lds_sync();
-    dft8_fwd(v);
-}
-
+// (A register-only form of transpose 1 — v_permlane32_swap / v_permlane16_swap / DPP row_ror:8, 40 instructions for 8 writes + 8
+// reads — lives in tools/ubench/xlane_t1.h: measured without gain in the FFT loop (profiles/r02_fftpad.md) and slower in the vocoder
+// pipeline, so the product does not carry it.)
 __device__ __forceinline__ void fft512_pad(cf (&v)[8], const FftLds& L)
 {
     fft512_pad_a(v, L);
@@ -455,7 +353,7 @@ __device__ __forceinline__ uint32_t atan2_q32(float im, float re)
     const uint32_t m_re = (uint32_t)((int32_t)__float_as_uint(re) >> 31), m_im = (uint32_t)((int32_t)__float_as_uint(im) >> 31);
     i = (i ^ m_re) + (m_re & 0x80000001u);
     i = (i ^ m_im) - m_im;
-    return ((ax + ay) < __builtin_inff()) ? i : 0u;        // a non-finite bin (NaN, Inf, or a sum that overflows) has phase 0
+    return ((ax + ay) < NAE_ATAN_HUGE) ? i : 0u;           // a bin of 2^100 or more — NaN, Inf, an overflowing sum included — has phase 0
 }
 
 // strided signal access: element (i) of one (stream, channel) at p[i * fs]

@@ -165,7 +165,7 @@ static float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 int32_t orc_atan2_q32(float im, float re)
 {
     const float ax = fabsf(re), ay = fabsf(im);
-    if (!((ax + ay) < INFINITY)) return 0;                /* a non-finite bin (NaN, Inf, or a sum that overflows) has phase 0 */
+    if (!((ax + ay) < NAE_ATAN_HUGE)) return 0;           /* a bin of 2^100 or more — NaN, Inf, an overflowing sum included — has phase 0 */
     float mx = ax > ay ? ax : ay;
     if (!(mx > NAE_ATAN_TINY)) mx = NAE_ATAN_TINY;
     const float mn = ax > ay ? ay : ax;

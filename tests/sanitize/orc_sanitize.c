@@ -5,6 +5,15 @@
 #include <stdlib.h>
 int main(void)
 {
+    /* atan2 revision 2 at the edges of its domain: huge finite bins, Inf, NaN, zeros (UBSan: no float -> int conversion out of range) */
+    {
+        const float edge[] = {0.0f, -0.0f, 1e-38f, 1e-35f, 1.0f, -1.0f, 1.2676506e30f, 3e38f, -3e38f, 2e38f, (float)(1.0 / 0.0), -(float)(1.0 / 0.0), (float)(0.0 / 0.0)};
+        const unsigned n = sizeof edge / sizeof edge[0];
+        long acc = 0;
+        for (unsigned a = 0; a < n; a++)
+            for (unsigned b = 0; b < n; b++) acc += orc_atan2_q32(edge[a], edge[b]) & 1;
+        printf("atan2 edges: %ld\n", acc);
+    }
     const int cases[][3] = {{48000, 2, 30000}, {44100, 1, 25000}, {8000, 2, 9000}, {22050, 1, 500}, {48000, 2, 0}};
     const double rp[][2] = {{1.0, 1.189207115}, {1.0, 0.8}, {1.5, 0.6666666}, {0.8, 1.0}, {1.0, 1.0}, {2.0, 0.5}};
     for (unsigned c = 0; c < sizeof cases / sizeof cases[0]; c++)

@@ -93,3 +93,37 @@ def test_no_diagnostic_scaffolding_in_product_sources():
     assert pipe.count("/*A*/") == 3 and pipe.count("/*B*/") == 3 and "/*pipe:begin*/" in pipe and "/*pipe:r1-end*/" in pipe
     inc = open(os.path.join(ROOT, "tools", "pipe_stamps", "stamps.inc")).read()
     assert "g_pipe_stamps" in inc
+
+
+def test_contexts_from_two_threads_keep_the_header_promise(nae):
+    """include/nae_gpu.h "Threads": no process-global mutable state; contexts may be created from different threads concurrently.
+    Without a GPU every creation fails loudly (NAE_ERR_HIP) from both threads and nothing crashes; with one, both succeed.  The GPU
+    suite drives two contexts from two threads through the kernels (tests/test_gpu_multi_ctx.py)."""
+    import ctypes as C
+    import threading
+    text = open(os.path.join(ROOT, "include", "nae_gpu.h")).read()
+    assert "Threads." in text and "ONE thread at a time drives a given context" in text
+    lib = nae.load_library()
+    rcs = []
+
+    def worker():
+        for _ in range(20):
+            h = C.c_void_p()
+            rc = lib.nae_ctx_create(0, C.byref(h))
+            rcs.append(rc)
+            if rc == 0:
+                lib.nae_ctx_destroy(h)
+
+    threads = [threading.Thread(target=worker) for _ in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert len(rcs) == 40
+    expect = 0 if lib.nae_device_count() > 0 else -3          # NAE_ERR_HIP: no usable device, no CPU fallback
+    assert set(rcs) == {expect}, set(rcs)
+    # no process-wide device latch is left in the library (round 3: g_nae_device)
+    src = open(os.path.join(ROOT, "nodey-audio-editor_amd", "csrc", "nae_api.hip")).read()
+    assert "g_nae_device" not in src
+    pipe = open(os.path.join(ROOT, "nodey-audio-editor_amd", "csrc", "kernels_pvpipe.hip")).read()
+    assert "static bool attr_done" not in pipe

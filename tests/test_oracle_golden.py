@@ -172,6 +172,12 @@ def test_atan2_q32():
     assert L.orc_atan2_q32(-1.0, 0.0) == -2 ** 30
     assert L.orc_atan2_q32(1.0, 1.0) in range(2 ** 29 - 400, 2 ** 29 + 400)
     assert L.orc_atan2_q32(1e-35, 1e-35) in range(0, 20000)  # a vanishing bin (below 2^-100) has a near-zero phase, not 1/8 turn
+    # bins of 2^100 or more have phase 0 by specification (the integer reciprocal seed would wrap beyond 1.6e38): finite huge values,
+    # Inf and NaN alike — and just below the cut the result is an ordinary phase
+    for im, re in ((1.0, 3e38), (3e38, 1.0), (-3e38, -3e38), (2.0 ** 100, 0.0), (0.0, -(2.0 ** 100)), (np.inf, 1.0), (1.0, np.nan), (2e38, 2e38)):
+        assert L.orc_atan2_q32(im, re) == 0, (im, re)
+    assert L.orc_atan2_q32(2.0 ** 99, 0.0) == 2 ** 30 and L.orc_atan2_q32(0.0, -(2.0 ** 99)) == -2 ** 31
+    assert abs(L.orc_atan2_q32(2.0 ** 98, 2.0 ** 98) - 2 ** 29) < 400
 
 
 def test_k7_properties_and_regression(golden):
