@@ -13,7 +13,7 @@
 //                  (row = unit mod R) so that a half-wave reads consecutive LDS words: conflict-free.
 //                  VALU-bound: 13 flop per candidate per 4 floats (4 mul + 4 add correlation, 1 mul + 4 add norm).
 //   st_aa_kernel   64-tap FIR, 4 consecutive outputs per thread from a 67-frame register window, even and odd taps
-//                  summed separately (the SSE stereo order); mono accumulates in double.
+//                  summed separately (the SSE stereo order); mono: one float accumulator, taps in order.
 //   st_cu_kernel   4-point cubic read at host-tabulated positions (the position accumulator is a sequential
 //                  double recurrence that does not depend on the audio: st_chain.h).
 #include "st_chain.h"
@@ -510,10 +510,10 @@ __global__ __launch_bounds__(256, 8) void st_aa_kernel(DView in, AaParams p, DOu
     // 8 taps per trip: frames m = kb .. kb+10 feed outputs i = 0..3 with tap k = m - i.  Every accumulator still sees
     // its taps in increasing order (the order is observable: results are compared bit for bit).
     float ev[4][CH], od[4][CH];
-    double acc[4];
+    float acc[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        acc[i] = 0.0;
+        acc[i] = 0.0f;
 #pragma unroll
         for (int c = 0; c < CH; c++) ev[i][c] = od[i][c] = 0.0f;
     }
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(256, 8) void st_aa_kernel(DView in, AaParams p, DOu
                             else od[i][c] = od[i][c] + x[t][c] * h[k];
                         }
                     } else {
-                        acc[i] += (double)(x[t][0] * h[k]);      // generic mono order: float products summed in double
+                        acc[i] = acc[i] + x[t][0] * h[k];        // generic mono order: one float accumulator, taps in order
                     }
                 }
             }
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(256, 8) void st_aa_kernel(DView in, AaParams p, DOu
 #pragma unroll
             for (int c = 0; c < CH; c++) y[i].x[c] = od[i][c] + ev[i][c];
         } else {
-            y[i].x[0] = (float)acc[i];
+            y[i].x[0] = acc[i];
         }
     }
     if (!kCubic) {

@@ -145,8 +145,9 @@ int nae_ensure_rs_table(nae_ctx* ctx, double rate_eff)
 }
 
 // Shape of the phase vocoder for a block call: frames per step of the pipeline (kernels_pvpipe.hip), synthesis tile, pass-1 tile.
-//   * >= 1024 stream-channels: four stream-channels per workgroup (frames_per_step 1), ONE tile per stream-channel — no
-//     pass 1, nothing analysed twice; from 2048 stream-channels two workgroups share a CU.
+//   * more than 3 stream-channels per CU (>= 1024 at 256 CUs, e.g. 512 stereo streams): four stream-channels per workgroup
+//     (frames_per_step 1), ONE tile per stream-channel — no pass 1, nothing analysed twice; from 2048 stream-channels two
+//     workgroups share a CU.  (2 to 3 per CU: the frame-interleaved shape below in three rounds, see the code.)
 //   * fewer: the four slots of a workgroup work on 2 or 4 consecutive frames of one stream-channel (frame-interleaved), so
 //     256 stream-channels (the 128 streams one rank of an 8-GPU job owns) still give every CU a workgroup without cutting
 //     a stream into time tiles.  A workgroup of these modes fills a CU's LDS alone: 4 frames per step up to n_cu
@@ -159,6 +160,10 @@ int nae_pick_pv_shape(nae_ctx* ctx, size_t frames, size_t n_sc, int* phase_tile,
 {
     const size_t n_cu = (size_t)(ctx->n_cu > 0 ? ctx->n_cu : 256);
     int fps = n_sc > 2 * n_cu ? 1 : n_sc > n_cu ? 2 : 4;
+    // between 2 and 3 stream-channels per CU four stream-channels per workgroup leave a quarter to a half of the CUs without a
+    // workgroup; three rounds of four-frames-per-step workgroups are faster there (profiles/r04_shape_sweep.md: 768 stream-channels
+    // 3.28 against 3.65 ms, 520: 3.21 against 3.35; at 1024 stream-channels one full round of the first shape wins again)
+    if (n_sc > 2 * n_cu && n_sc <= 3 * n_cu) fps = 4;
     if (ctx->pv_fps == 1 || ctx->pv_fps == 2 || ctx->pv_fps == 4) fps = ctx->pv_fps;
     *frames_per_step = fps;
     if (ctx->pv_tile > 0) { *phase_tile = ctx->pv_tile; return ctx->pv_tile; }

@@ -56,6 +56,7 @@ int swr_plan_make(int in_rate, int out_rate, SwrPlan* p)
     p->factor = (double)out_rate * NAE_SWR_CUTOFF / (double)in_rate;
     if (p->factor > 1.0) p->factor = 1.0;
     p->L = (int)ceil(NAE_SWR_FILTER_SIZE / p->factor);
+    if (p->L > 1) p->L = (p->L + 1) & ~1;          // the library rounds a multi-tap filter up to an even length
     if (p->L < 1) p->L = 1;
     if (p->L > NAE_SWR_MAX_TAPS) return NAE_ERR_UNSUPPORTED;
     p->alloc = (p->L + 7) & ~7;

@@ -61,6 +61,9 @@ int orc_swr_plan_make(int in_rate, int out_rate, orc_swr_plan* p)
     if (p->factor > 1.0) p->factor = 1.0;
     p->filter_length = (int)ceil(NAE_SWR_FILTER_SIZE / p->factor);
     if (p->filter_length < 1) p->filter_length = 1;
+    /* resample_init rounds a filter longer than one tap up to an EVEN length (FFALIGN(filter_length, 2)) before it builds the
+     * bank: 88.2 -> 48 kHz gives 62 taps, not 61 (restated from public knowledge of FFmpeg 7.1's resample.c; UNPINNED) */
+    if (p->filter_length > 1) p->filter_length = (p->filter_length + 1) & ~1;
     if (p->filter_length > NAE_SWR_MAX_TAPS) return -2;
     p->filter_alloc = (p->filter_length + 7) & ~7;
     const long long num = out_rate, den = (long long)in_rate * p->phase_count;

@@ -292,14 +292,15 @@ static void aa_process(aa_t* a, fifo* out)
                 dst[2 * j + (size_t)c] = od + ev;
             }
     } else {
-        /* generic mono kernel: float products accumulated in double, in tap order */
+        /* generic mono kernel: products accumulated in tap order in LONG_SAMPLETYPE, which SoundTouch >= 2.1 typedefs as FLOAT in
+         * float builds ("to enable efficient autovectorization", STTypes.h) — rounds 1-3 restated the older double accumulator */
         count = n - AA_LEN;
         if (count == 0) return;
         float* dst = fifo_end(out, count);
         for (size_t j = 0; j < count; j++) {
-            double s = 0.0;
-            for (int k = 0; k < AA_LEN; k++) s += src[j + (size_t)k] * a->coef[k];
-            dst[j] = (float)s;
+            float s = 0.0f;
+            for (int k = 0; k < AA_LEN; k++) s = s + src[j + (size_t)k] * a->coef[k];
+            dst[j] = s;
         }
     }
     fifo_commit(out, count);

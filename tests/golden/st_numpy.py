@@ -109,7 +109,7 @@ def aa_coefficients(rate):
 
 def aa_block(x, ch, coef):
     """64-tap FIR: out[j] = sum_k x[j+k] c[k]; stereo: even and odd taps summed separately (an even count of outputs);
-    mono: float products accumulated in double"""
+    mono: float products accumulated in float, in tap order"""
     n = x.shape[0]
     if n < 64:
         return np.zeros((0, ch), f32)
@@ -124,8 +124,7 @@ def aa_block(x, ch, coef):
         ev = _seq_sum(prod[:, :, 0::2], 2)
         od = _seq_sum(prod[:, :, 1::2], 2)
         return (od + ev).astype(f32)
-    acc = np.cumsum(prod.astype(np.float64), axis=2)[:, :, -1]
-    return acc.astype(f32)
+    return _seq_sum(prod, 2).astype(f32)            # LONG_SAMPLETYPE is float in SoundTouch >= 2.1 float builds
 
 
 def cu_block(x, ch, rate):

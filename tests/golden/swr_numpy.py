@@ -28,6 +28,8 @@ def bank64(in_rate, out_rate):
     P = phase_count(in_rate, out_rate)
     factor = min(out_rate * CUTOFF / in_rate, 1.0)
     L = max(int(ceil(FILTER_SIZE / factor)), 1)
+    if L > 1:
+        L = (L + 1) & ~1                      # resample_init: FFALIGN(filter_length, 2) for filters longer than one tap
     center = (L - 1) // 2
     i = np.arange(L)[None, :]
     ph = np.arange(P)[:, None]
@@ -72,7 +74,7 @@ def main():
     for name, x in signals().items():
         x32 = x.astype(np.float32)
         out[f"{name}_in"] = x32
-        for in_rate, out_rate in ((44100, 48000), (22050, 48000), (96000, 48000), (8000, 48000)):
+        for in_rate, out_rate in ((44100, 48000), (22050, 48000), (96000, 48000), (8000, 48000), (88200, 48000)):   # 88.2 kHz: 61 -> 62 taps
             out[f"{name}_{in_rate}_{out_rate}"] = resample64(x32, in_rate, out_rate)
     np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "swr_golden.npz"), **out)
     print({k: v.shape for k, v in out.items()})

@@ -397,7 +397,7 @@ def test_n2_queued_convert_equals_host_convert(ctx, nae, fmt_name, in_rate, ch):
     assert_bits(b[1], a[1], f"{fmt_name} R")
 
 
-@pytest.mark.parametrize("in_rate", [44100, 22050, 96000, 8000])
+@pytest.mark.parametrize("in_rate", [44100, 22050, 96000, 8000, 88200])
 def test_n2_resampler_golden_and_chunking(ctx, nae, golden, in_rate):
     """the swr-default resampler on the golden signals: bit-exact vs the oracle, <= 1e-4 relative RMS vs the float64
     golden (tests/golden/swr_numpy.py), and independent of how the input is cut into swr_convert calls"""

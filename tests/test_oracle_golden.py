@@ -241,7 +241,7 @@ def test_k7_parameter_envelope():
     assert rc == 0 and pl.out_len == 0
 
 
-@pytest.mark.parametrize("in_rate", [44100, 22050, 96000, 8000])
+@pytest.mark.parametrize("in_rate", [44100, 22050, 96000, 8000, 88200])
 def test_n2_swr_oracle_matches_float64_golden(golden, in_rate):
     """oracle/orc_swr.c (libswresample's default resampler, restated; UNPINNED versus FFmpeg) against the independent float64
     restatement of the same specification (tests/golden/swr_numpy.py): same output count, <= 1e-4 relative RMS"""
@@ -259,6 +259,8 @@ def test_n2_swr_plan_and_edges():
     assert rc == 0 and (pl.filter_length, pl.phase_count, pl.src_incr, pl.dst_incr_div, pl.dst_incr_mod) == (32, 160, 1, 147, 0)
     rc, pl = orc.swr_plan(96000, 48000)                     # down-conversion: the filter stretches by 1 / (0.5 * 0.97); 1 / 2 -> one phase
     assert rc == 0 and pl.filter_length == 66 and pl.phase_count == 1
+    rc, pl = orc.swr_plan(88200, 48000)                     # ceil(32 / 0.5279) = 61 taps, rounded up to an EVEN 62 as resample_init does
+    assert rc == 0 and pl.filter_length == 62 and pl.phase_count == 80
     assert [orc.swr_plan(r, 48000)[1].phase_count for r in (22050, 8000, 32000, 11025)] == [320, 6, 3, 640]
     rc, pl = orc.swr_plan(44101, 48000)                     # a ratio that does not reduce keeps 2^phase_shift phases (nearest phase)
     assert rc == 0 and pl.phase_count == 1024
