@@ -53,7 +53,7 @@ def parse():
     return ap.parse_args()
 
 
-def host_path(seconds=10.0):
+def host_path(seconds=30.0):
     """The plugin boundary as the editor sees it (include/infra/processor.hpp:108-113): 1152-sample frames through
     audio_volume_adjust -> audio_amix(2) -> pitch_modifier in the C++ host mirror's fiber runner (one thread, every hop a host frame),
     one branch and 16 independent branches.  Runs tests/host/selftest (test code: it checks branch 0 against the oracle and times the

@@ -3,6 +3,8 @@
 #include <deque>
 #include "gpu-context.hpp"
 
+#include <cstring>
+
 #include <algorithm>
 #include <cmath>
 #include <deque>
@@ -189,6 +191,7 @@ namespace processor
 
 		nae_ctx* ctx = gpu::context();
 		gpu::Device_buffer d_in, d_out;
+		gpu::Pinned_buffer h_in, h_out;
 
 		// Batching.  The reference takes one frame per input and round and mixes it; a 1152-sample round is
 		// 9 KB per input, so on the GPU a round is all launch and wait.  Here every frame that is ALREADY waiting joins: the
@@ -255,10 +258,73 @@ namespace processor
 				if (!any) break;
 			}
 
-			float* di = static_cast<float*>(d_in.reserve(in_floats * sizeof(float)));
+			// Fast path: the leading rounds in which EVERY input has a frame that needs no conversion — 48 kHz stereo float (packed or
+			// planar, the format an input had in the batch's first round), all of one length S, no remainder waiting in a converter.
+			// Their frames are copied into page-locked staging and go up as ONE asynchronous copy; ONE launch mixes all of these
+			// rounds (rounds as "streams" of nae_amix_sig_f32: the arithmetic of nae_amix_f32, same bits).  Everything else — other
+			// rates or formats, mono, rounds of unequal frame lengths, the drain rounds behind an ended input — takes the converter
+			// path below, one round at a time, in a later turn if fast rounds lead the batch.
+			size_t fast = 0;
+			for (size_t b = 0; b < rounds.size(); b++)
+			{
+				bool ok = rounds[b].S == rounds[0].S;
+				for (int i = 0; i < input_num && ok; i++)
+				{
+					if (buffers[i].size() <= b) { ok = false; break; }
+					const Frame_data* f = buffers[i][b]->data();
+					ok = f->sample_rate == std_sample_rate && f->ch_layout.nb_channels == 2 && f->nb_samples == rounds[0].S &&
+						 (f->format == AV_SAMPLE_FMT_FLT || f->format == AV_SAMPLE_FMT_FLTP) && f->format == buffers[i][0]->data()->format &&
+						 (resamplers[i].h == nullptr || nae_swr_buffered(resamplers[i].h) == 0);
+				}
+				if (!ok) break;
+				fast++;
+			}
+			if (fast > 0) rounds.resize(fast);
+			out_floats = 0;
+			for (const Round& r : rounds) out_floats += 2 * r.plane;
+
 			float* dout = static_cast<float*>(d_out.reserve(out_floats * sizeof(float)));
-			if (in_floats) gpu::check(nae_memset(ctx, di, 0, in_floats * sizeof(float)), "nae_memset");  // zero-filled planes [round][i][2][S]
+			float* hout = static_cast<float*>(h_out.reserve(out_floats * sizeof(float)));
 			size_t done = 0;
+			if (fast > 0)
+			{
+				const int S = rounds[0].S;
+				const size_t plane = rounds[0].plane, slot = 2 * plane;      // one input frame: [S][2] packed or [2][plane] planar
+				const size_t n_floats = fast * (size_t)input_num * slot;
+				float* di = static_cast<float*>(d_in.reserve(n_floats * sizeof(float)));
+				float* hin = static_cast<float*>(h_in.reserve(n_floats * sizeof(float)));
+				std::vector<nae_sig> sigs(input_num);
+				for (int i = 0; i < input_num; i++)
+				{
+					const bool planar = buffers[i][0]->data()->format == AV_SAMPLE_FMT_FLTP;
+					sigs[i] = planar ? nae_sig{di + (size_t)i * slot, (size_t)input_num * slot, plane, 1} : nae_sig{di + (size_t)i * slot, (size_t)input_num * slot, 1, 2};
+					for (size_t b = 0; b < fast; b++)
+					{
+						const Frame_data* f = buffers[i][b]->data();
+						float* dst = hin + (b * (size_t)input_num + (size_t)i) * slot;
+						if (planar)
+						{
+							std::memcpy(dst, f->data[0], (size_t)S * sizeof(float));
+							std::memcpy(dst + plane, f->data[1], (size_t)S * sizeof(float));
+						}
+						else
+							std::memcpy(dst, f->data[0], (size_t)S * 2 * sizeof(float));
+					}
+				}
+				gpu::check(nae_memcpy_h2d(ctx, di, hin, n_floats * sizeof(float)), "h2d");
+				const nae_sig out_sig{dout, slot, plane, 1};
+				gpu::check(nae_amix_sig_f32(ctx, sigs.data(), volumes.data(), input_num, &out_sig, (size_t)S, fast), "nae_amix_sig_f32");
+				for (Round& r : rounds)
+				{
+					time_seconds += r.S / double(std_sample_rate);          // :199 (pts = END time of the frame)
+					r.out = new_fltp_frame(r.S, time_seconds);
+					done++;
+				}
+			}
+			else
+			{
+			float* di = static_cast<float*>(d_in.reserve(in_floats * sizeof(float)));
+			if (in_floats) gpu::check(nae_memset(ctx, di, 0, in_floats * sizeof(float)), "nae_memset");  // zero-filled planes [round][i][2][S]
 			for (Round& r : rounds)
 			{
 				const size_t b = done;
@@ -281,12 +347,18 @@ namespace processor
 				}
 				float* o = dout + r.out_off;
 				gpu::check(nae_amix_f32(ctx, inL, inR, volumes.data(), input_num, o, o + r.plane, r.S), "nae_amix_f32");
-				gpu::check(nae_memcpy_d2h(ctx, r.out->data()->data[0], o, r.S * sizeof(float)), "d2h");
-				gpu::check(nae_memcpy_d2h(ctx, r.out->data()->data[1], o + r.plane, r.S * sizeof(float)), "d2h");
 				done++;
 				if (count == input_num) { finished = true; break; }  // :320
 			}
-			gpu::wait(stop_token);  // the buffered frames (the uploads' sources) are released only now
+			}
+			// all mixed rounds come down as ONE asynchronous copy into page-locked staging
+			if (done) gpu::check(nae_memcpy_d2h(ctx, hout, dout, (rounds[done - 1].out_off + 2 * rounds[done - 1].plane) * sizeof(float)), "d2h");
+			gpu::wait(stop_token);  // the buffered frames (the converter path's upload sources) are released only now
+			for (size_t k = 0; k < done; k++)
+			{
+				std::memcpy(rounds[k].out->data()->data[0], hout + rounds[k].out_off, (size_t)rounds[k].S * sizeof(float));
+				std::memcpy(rounds[k].out->data()->data[1], hout + rounds[k].out_off + rounds[k].plane, (size_t)rounds[k].S * sizeof(float));
+			}
 			batch_stats.rounds += done;
 			batch_stats.waits++;
 

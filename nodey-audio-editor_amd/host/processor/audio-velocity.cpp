@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 
 namespace processor
 {
@@ -36,33 +37,37 @@ namespace processor
 		}
 
 		// construct_audio_frame_float, audio-velocity.cpp:234-263 (time_us is a FLOAT there: 24-bit pts quirk kept)
-		std::shared_ptr<Audio_frame> construct_audio_frame_float(const std::vector<float>& samples, int sample_rate,
+		std::shared_ptr<Audio_frame> construct_audio_frame_float(const float* samples, size_t n_frames, int sample_rate,
 																 int channel_count, float time_us)
 		{
 			auto new_frame = std::make_shared<Audio_frame>();
 			Frame_data* frame = new_frame->data();
 			frame->sample_rate = sample_rate;
 			frame->ch_layout.nb_channels = channel_count;
-			frame->nb_samples = static_cast<int>(samples.size() / channel_count);
+			frame->nb_samples = static_cast<int>(n_frames);
 			frame->format = AV_SAMPLE_FMT_FLT;
 			frame->time_base = {1, 1000000};
 			frame->pts = static_cast<int64_t>(time_us);
 			frame_get_buffer(frame, 32);
-			std::copy(samples.begin(), samples.end(), reinterpret_cast<float*>(frame->data[0]));
+			std::memcpy(frame->data[0], samples, n_frames * channel_count * sizeof(float));
 			return new_frame;
 		}
 
-		// frames -> device interleaved f32, one after the other (extract_samples_interleaved, :150-232, as
-		// nae_to_f32_interleaved per frame).  Everything is queued on the stream; the frames must stay alive until the caller
-		// has waited for it.  All frames have the channel count of the first.
-		float* upload_as_f32(const std::vector<std::shared_ptr<const Audio_frame>>& frames, gpu::Device_buffer& d_raw,
+		// frames -> device interleaved f32, one after the other (extract_samples_interleaved, :150-232).  The frames of a batch are
+		// copied into page-locked staging on the CPU and go up as ONE asynchronous copy; on the device
+		//   * packed float frames (and mono planar ones) already ARE the interleaved signal: no kernel at all;
+		//   * a run of planar stereo float frames of equal length is interleaved by ONE strided launch (frames as "streams");
+		//   * integer formats: nae_to_f32_interleaved per frame (the reference's literal divisors).
+		// Everything is queued on the stream.  All frames have the channel count of the first.
+		float* upload_as_f32(const std::vector<std::shared_ptr<const Audio_frame>>& frames, gpu::Pinned_buffer& h_raw, gpu::Device_buffer& d_raw,
 							 gpu::Device_buffer& d_f32, size_t* total_samples)
 		{
 			nae_ctx* ctx = gpu::context();
 			const int ch = frames.front()->data()->ch_layout.nb_channels;
-			struct Place { size_t raw_off, stride, plane_bytes, out_off; int planes; };
+			struct Place { size_t raw_off, stride, plane_bytes, out_off; int planes; bool wire; };
 			std::vector<Place> place;
 			size_t raw_bytes = 0, out_samples = 0;
+			bool all_wire = true;
 			for (const auto& f : frames)
 			{
 				const Frame_data* frame = f->data();
@@ -76,25 +81,68 @@ namespace processor
 				Place p;
 				p.planes = planar ? ch : 1;
 				p.plane_bytes = (size_t)frame->nb_samples * bps * (planar ? 1 : ch);
-				p.stride = (p.plane_bytes + 255) / 256 * 256;
+				p.wire = frame->format == AV_SAMPLE_FMT_FLT || (frame->format == AV_SAMPLE_FMT_FLTP && ch == 1);
+				all_wire = all_wire && p.wire;
+				// float planes lie back to back ([frame][ch][n]: what the strided interleave launch reads); integer planes start on 256 bytes
+				const bool f32 = frame->format == AV_SAMPLE_FMT_FLT || frame->format == AV_SAMPLE_FMT_FLTP;
+				p.stride = f32 ? p.plane_bytes : (p.plane_bytes + 255) / 256 * 256;
+				raw_bytes = f32 ? (raw_bytes + 15) / 16 * 16 : (raw_bytes + 255) / 256 * 256;
 				p.raw_off = raw_bytes;
 				p.out_off = out_samples * ch;
 				raw_bytes += p.stride * p.planes;
 				out_samples += frame->nb_samples;
 				place.push_back(p);
 			}
-			auto* raw = static_cast<uint8_t*>(d_raw.reserve(raw_bytes));
+			*total_samples = out_samples;
+			auto* host = static_cast<uint8_t*>(h_raw.reserve(raw_bytes));
 			float* out = static_cast<float*>(d_f32.reserve(out_samples * ch * sizeof(float)));
+			if (all_wire)
+			{
+				// the staged bytes are the interleaved signal (offsets re-packed without the 16-byte rounding)
+				size_t off = 0;
+				for (size_t k = 0; k < frames.size(); k++)
+				{
+					std::memcpy(host + off, frames[k]->data()->data[0], place[k].plane_bytes);
+					off += place[k].plane_bytes;
+				}
+				gpu::check(nae_memcpy_h2d(ctx, out, host, off), "h2d");
+				return out;
+			}
+			auto* raw = static_cast<uint8_t*>(d_raw.reserve(raw_bytes));
 			for (size_t k = 0; k < frames.size(); k++)
+				for (int q = 0; q < place[k].planes; q++)
+					std::memcpy(host + place[k].raw_off + q * place[k].stride, frames[k]->data()->data[q], place[k].plane_bytes);
+			gpu::check(nae_memcpy_h2d(ctx, raw, host, raw_bytes), "h2d");
+			for (size_t k = 0; k < frames.size();)
 			{
 				const Frame_data* frame = frames[k]->data();
 				const Place& p = place[k];
-				const void* pl[2] = {raw + p.raw_off, raw + p.raw_off + p.stride};
-				for (int q = 0; q < p.planes; q++)
-					gpu::check(nae_memcpy_h2d(ctx, raw + p.raw_off + q * p.stride, frame->data[q], p.plane_bytes), "h2d");
-				gpu::check(nae_to_f32_interleaved(ctx, frame->format, pl, frame->nb_samples, ch, out + p.out_off), "nae_to_f32_interleaved");
+				if (p.wire)
+				{
+					gpu::check(nae_memcpy_d2d(ctx, out + p.out_off, raw + p.raw_off, p.plane_bytes), "d2d");
+					k++;
+				}
+				else if (frame->format == AV_SAMPLE_FMT_FLTP)
+				{
+					// run of planar stereo frames of this length, staged at a constant pitch
+					const size_t n = (size_t)frame->nb_samples;
+					size_t run = 1;
+					while (k + run < frames.size() && frames[k + run]->data()->format == AV_SAMPLE_FMT_FLTP &&
+						   (size_t)frames[k + run]->data()->nb_samples == n && place[k + run].raw_off == p.raw_off + run * (place[k + 1].raw_off - p.raw_off))
+						run++;
+					const size_t pitch_floats = run > 1 ? (place[k + 1].raw_off - p.raw_off) / sizeof(float) : 2 * n;
+					const nae_sig src{raw + p.raw_off, pitch_floats, n, 1};
+					const nae_sig dst{out + p.out_off, 2 * n, 1, 2};
+					gpu::check(nae_copy_sig_f32(ctx, &src, &dst, n, 2, run), "nae_copy_sig_f32");
+					k += run;
+				}
+				else
+				{
+					const void* pl[2] = {raw + p.raw_off, raw + p.raw_off + p.stride};
+					gpu::check(nae_to_f32_interleaved(ctx, frame->format, pl, frame->nb_samples, ch, out + p.out_off), "nae_to_f32_interleaved");
+					k++;
+				}
 			}
-			*total_samples = out_samples;
 			return out;
 		}
 		// the object soundtouch_process_payload talks to: the phase-vocoder handle (default) or the
@@ -121,9 +169,9 @@ namespace processor
 			{
 				gpu::check(pv ? nae_stretch_put(pv, samples, n) : nae_wsola_put(st, samples, n), "stretch put");
 			}
-			void receive_host(float* dst, size_t max, size_t* got)
+			void receive_device(float* dst, size_t max, size_t* got)
 			{
-				gpu::check(pv ? nae_stretch_receive_host(pv, dst, max, got) : nae_wsola_receive_host(st, dst, max, got), "stretch receive");
+				gpu::check(pv ? nae_stretch_receive(pv, dst, max, got) : nae_wsola_receive(st, dst, max, got), "stretch receive");
 			}
 			void flush() { gpu::check(pv ? nae_stretch_flush(pv) : nae_wsola_flush(st), "stretch flush"); }
 		};
@@ -148,28 +196,51 @@ namespace processor
 				);
 			Audio_stream& input_stream = input_item.value().get();
 			Stretcher soundtouch;
-			gpu::Device_buffer d_raw, d_f32;
-			bool input_stream_eof = false;
+			gpu::Device_buffer d_raw, d_f32, d_out;
+			gpu::Pinned_buffer h_raw, h_out;
+			bool input_stream_eof = false, pending_put = false;
 			std::shared_ptr<const Audio_frame> held;  // popped, but with another channel count than the batch in front of it
 			const double time_ratio = 1.0f / velocity;
 			int channel_count = 0, sample_rate = 0;
 			double time_seconds = 0.0;
 
-			auto acquire_func = [&](int count)
+			// receiveSamples + construct_audio_frame_float + push (:294-316), for every chunk that is ready at once: the chunk sizes are
+			// those the reference's loop would take one per turn (min(numSamples, max) while more than `floor` samples are queued); all
+			// of them come down as ONE asynchronous copy into page-locked staging behind ONE wait, then they are cut into frames
+			auto acquire_chunks = [&](size_t floor, uint32_t max_samples)
 			{
-				std::vector<float> output_samples((size_t)count * channel_count);
-				size_t samples_read = 0;
+				std::vector<size_t> chunks;
+				size_t avail = soundtouch.available(), total = 0;
+				while (avail > floor)
+				{
+					const size_t take = std::min<size_t>(avail, std::max<uint32_t>(max_samples, 1));
+					chunks.push_back(take);
+					total += take;
+					avail -= take;
+				}
+				if (chunks.empty()) return;
+				nae_ctx* ctx = gpu::context();
+				float* dev = static_cast<float*>(d_out.reserve(total * channel_count * sizeof(float)));
+				float* host = static_cast<float*>(h_out.reserve(total * channel_count * sizeof(float)));
+				size_t got = 0;
+				soundtouch.receive_device(dev, total, &got);
+				gpu::check(nae_memcpy_d2h(ctx, host, dev, got * channel_count * sizeof(float)), "d2h");
 				gpu::wait(stop_token);
-				soundtouch.receive_host(output_samples.data(), count, &samples_read);
-				output_samples.resize(samples_read * channel_count);
-				auto new_frame = construct_audio_frame_float(output_samples, sample_rate, channel_count, (float)(time_seconds * 1000000));
-				time_seconds += double(samples_read) / sample_rate;
-				for (auto& stream : output_stream)
-					while (!stop_token)
-					{
-						if (stream->try_push(new_frame) == channel_op_status::success) break;
-						nae_fiber::this_fiber::yield();
-					}
+				size_t pos = 0;
+				for (const size_t take : chunks)
+				{
+					const size_t n = std::min(take, got - pos);
+					if (n == 0) break;
+					auto new_frame = construct_audio_frame_float(host + pos * channel_count, n, sample_rate, channel_count, (float)(time_seconds * 1000000));
+					time_seconds += double(n) / sample_rate;
+					pos += n;
+					for (auto& stream : output_stream)
+						while (!stop_token)
+						{
+							if (stream->try_push(new_frame) == channel_op_status::success) break;
+							nae_fiber::this_fiber::yield();
+						}
+				}
 			};
 
 			while (!stop_token)
@@ -225,11 +296,12 @@ namespace processor
 						// under one chunk again: the queue never grows beyond one batch.)
 						static_assert(max_queued_samples >= 16 * 1152 * 3, "a batch fits the reference's queue bound");
 						size_t total = 0;
-						float* samples = upload_as_f32(batch, d_raw, d_f32, &total);
+						float* samples = upload_as_f32(batch, h_raw, d_raw, d_f32, &total);
 						soundtouch.put(samples, total);
-						gpu::wait(stop_token);  // d_raw / d_f32 are reused by the next batch; the frames are released
+						// (no wait here: the frames were copied into page-locked staging and are released; staging and device buffers are
+						// next touched behind the wait of the receive below, or of the next turn's)
+						pending_put = true;
 						batch_stats.rounds += batch.size();
-						batch_stats.waits++;
 					}
 				}
 				if (soundtouch.open())
@@ -241,17 +313,24 @@ namespace processor
 					{
 						// the reference receives one chunk per loop turn because it puts one frame per turn (:403,416-424); a batched put
 						// makes several chunks available, and all of them are taken now (chunk sizes stay inside [min, max])
-						while (!stop_token && soundtouch.available() > min_samples)
-							acquire_func((int)std::min<size_t>(soundtouch.available(), max_samples));
+						acquire_chunks(min_samples, max_samples);
+						pending_put = false;
+						batch_stats.waits++;
 					}
 					else if (input_stream_eof)
 					{
 						soundtouch.flush();
 						// the reference emits ONE frame with everything that is left (:427-433); here flush() may release
 						// the whole stream, so it is cut into the same [min, max] chunks the steady state uses
-						while (!stop_token && soundtouch.available() > 0)
-							acquire_func((int)std::min<size_t>(soundtouch.available(), std::max<uint32_t>(max_samples, 1)));
+						acquire_chunks(0, max_samples);
 						break;
+					}
+					if (pending_put)
+					{
+						// a put that released nothing: its staging is reused by the next batch, so it is waited for now
+						gpu::wait(stop_token);
+						pending_put = false;
+						batch_stats.waits++;
 					}
 				}
 				else if (input_stream_eof)
@@ -350,20 +429,42 @@ namespace processor
 		nae_spectrum* spectrum = nullptr;
 		struct Guard { nae_spectrum*& h; ~Guard() { if (h) nae_spectrum_destroy(h); } } guard{spectrum};
 		gpu::Device_buffer d_raw, d_f32, d_out;
+		gpu::Pinned_buffer h_raw, h_out;
 		int ch = 0, sample_rate = 0;
 		double time_seconds = 0.0;
-		std::vector<float> host;
+		std::shared_ptr<const Audio_frame> held;  // popped, but with another channel count than the batch in front of it
 
 		while (!stop_token)
 		{
-			const auto pop_result = input_stream.try_pop();
-			if (!pop_result.has_value())
+			// every frame that is already waiting (at most 16) is uploaded and put as one block behind one wait (the handle's
+			// frames do not depend on how its input is cut into puts)
+			constexpr size_t max_batch = 16;
+			std::vector<std::shared_ptr<const Audio_frame>> batch;
+			if (held) batch.push_back(std::move(held));
+			held.reset();
+			bool ended = false;
+			while (batch.size() < max_batch)
 			{
-				if (input_stream.eof()) break;  // a trailing partial window produces no frame
+				const auto pop_result = input_stream.try_pop();
+				if (!pop_result.has_value())
+				{
+					ended = input_stream.eof();
+					break;
+				}
+				if (!batch.empty() && pop_result.value()->data()->ch_layout.nb_channels != batch.front()->data()->ch_layout.nb_channels)
+				{
+					held = pop_result.value();
+					break;
+				}
+				batch.push_back(pop_result.value());
+			}
+			if (batch.empty())
+			{
+				if (ended) break;  // a trailing partial window produces no frame
 				nae_fiber::this_fiber::yield();
 				continue;
 			}
-			const Frame_data* frame = pop_result.value()->data();
+			const Frame_data* frame = batch.front()->data();
 			if (spectrum == nullptr)
 			{
 				ch = frame->ch_layout.nb_channels;
@@ -373,16 +474,16 @@ namespace processor
 				gpu::check(nae_spectrum_create(ctx, 1024, 256, ch, &spectrum), "nae_spectrum_create");
 			}
 			size_t total = 0;
-			float* samples = upload_as_f32({pop_result.value()}, d_raw, d_f32, &total);
+			float* samples = upload_as_f32(batch, h_raw, d_raw, d_f32, &total);
 			gpu::check(nae_spectrum_put(spectrum, samples, total), "nae_spectrum_put");
 			const size_t ready = nae_spectrum_available(spectrum);
 			if (ready == 0) { gpu::wait(stop_token); continue; }
 			const size_t rec = (size_t)ch * 513;
 			float* dout = static_cast<float*>(d_out.reserve(ready * rec * sizeof(float)));
+			float* host = static_cast<float*>(h_out.reserve(ready * rec * sizeof(float)));
 			size_t got = 0;
 			gpu::check(nae_spectrum_receive(spectrum, dout, ready, &got), "nae_spectrum_receive");
-			host.resize(got * rec);
-			gpu::check(nae_memcpy_d2h(ctx, host.data(), dout, host.size() * sizeof(float)), "d2h");
+			gpu::check(nae_memcpy_d2h(ctx, host, dout, got * rec * sizeof(float)), "d2h");
 			gpu::wait(stop_token);
 			for (size_t f = 0; f < got && !stop_token; f++)
 			{
@@ -395,8 +496,7 @@ namespace processor
 				o->time_base = {1, 1000000};
 				o->pts = (int64_t)(time_seconds * 1000000);
 				frame_get_buffer(o, 32);
-				for (int c = 0; c < ch; c++)
-					std::copy(host.begin() + (f * ch + c) * 513, host.begin() + (f * ch + c + 1) * 513, reinterpret_cast<float*>(o->data[c]));
+				for (int c = 0; c < ch; c++) std::memcpy(o->data[c], host + (f * ch + c) * 513, 513 * sizeof(float));
 				time_seconds += 256.0 / sample_rate;
 				for (auto& stream : output_stream)
 					while (!stop_token && stream->try_push(out) != channel_op_status::success) nae_fiber::this_fiber::yield();

@@ -1,6 +1,8 @@
 #include "audio-vol.hpp"
 #include "gpu-context.hpp"
 
+#include <cstring>
+
 namespace processor
 {
 	static std::vector<infra::Processor::Pin_attribute> io_pins()
@@ -53,6 +55,7 @@ namespace processor
 
 		nae_ctx* ctx = gpu::context();
 		gpu::Device_buffer d_src, d_dst;
+		gpu::Pinned_buffer h_src, h_dst;
 		batch_stats = {};
 
 		// Batching: one launch per frame is launch-bound (a 1152-sample frame is 9 KB), so every
@@ -134,19 +137,22 @@ namespace processor
 
 			auto* s = static_cast<uint8_t*>(d_src.reserve(total));
 			auto* d = static_cast<uint8_t*>(d_dst.reserve(total));
+			// the batch goes up and comes back as ONE asynchronous copy each, through page-locked staging (gpu::Pinned_buffer)
+			auto* hs = static_cast<uint8_t*>(h_src.reserve(total));
+			auto* hd = static_cast<uint8_t*>(h_dst.reserve(total));
 			for (const Slot& slot : batch)
-				for (int p = 0; p < slot.planes; p++)
-					gpu::check(nae_memcpy_h2d(ctx, s + slot.offset[p], slot.src->data()->data[p], slot.plane_bytes), "h2d");
+				for (int p = 0; p < slot.planes; p++) std::memcpy(hs + slot.offset[p], slot.src->data()->data[p], slot.plane_bytes);
+			gpu::check(nae_memcpy_h2d(ctx, s, hs, total), "h2d");
 			// the flat view of the batch as ONE packed mono plane of the sample type (the pad bytes between planes are
 			// scaled too and never read back); `volume` is read once per batch, as the reference reads it once per frame
 			const void* sp[1] = {s};
 			void* dp[1] = {d};
 			const int packed = planar ? (format == AV_SAMPLE_FMT_FLTP ? AV_SAMPLE_FMT_FLT : format == AV_SAMPLE_FMT_S16P ? AV_SAMPLE_FMT_S16 : AV_SAMPLE_FMT_S32) : format;
 			gpu::check(nae_gain_frame(ctx, packed, sp, dp, total / bps, 1, volume), "nae_gain_frame");
-			for (const Slot& slot : batch)
-				for (int p = 0; p < slot.planes; p++)
-					gpu::check(nae_memcpy_d2h(ctx, slot.dst->data()->data[p], d + slot.offset[p], slot.plane_bytes), "d2h");
+			gpu::check(nae_memcpy_d2h(ctx, hd, d, total), "d2h");
 			gpu::wait(stop_token);
+			for (const Slot& slot : batch)
+				for (int p = 0; p < slot.planes; p++) std::memcpy(slot.dst->data()->data[p], hd + slot.offset[p], slot.plane_bytes);
 			batch_stats.rounds += batch.size();
 			batch_stats.waits++;
 			for (const Slot& slot : batch) push_frame(slot.dst);

@@ -17,7 +17,10 @@
 #include "../infra/processor.hpp"
 
 #include <atomic>
+#include <chrono>
 #include <cstdlib>
+#include <map>
+#include <vector>
 
 namespace processor::gpu
 {
@@ -25,15 +28,23 @@ namespace processor::gpu
 	// nodes had a batch in flight at the same moment
 	struct Flight_stats
 	{
-		size_t waits = 0, polls = 0, nodes = 0;
+		size_t waits = 0, polls = 0, nodes = 0, contexts_created = 0;
 		int in_flight = 0, max_in_flight = 0;
 		int devices_used = 0;
+		double setup_seconds = 0.0;  // spent creating contexts and (re)allocating device / page-locked buffers
+	};
+	struct Setup_timer
+	{
+		std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+		~Setup_timer();
 	};
 	inline Flight_stats& flight_stats()
 	{
 		static Flight_stats s;
 		return s;
 	}
+
+	inline Setup_timer::~Setup_timer() { flight_stats().setup_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
 
 	inline int pick_device()
 	{
@@ -48,8 +59,25 @@ namespace processor::gpu
 		return d;
 	}
 
+	// contexts that finished nodes have given back, per device: the editor starts a new Runner for every preview / export
+	// (frontend/app.cpp:2001-2094), and a context (stream + tables) costs a millisecond or two to create
+	inline std::map<int, std::vector<nae_ctx*>>& context_pool()
+	{
+		static std::map<int, std::vector<nae_ctx*>> pool;
+		return pool;
+	}
+
 	inline nae_ctx* create_context(int device)
 	{
+		auto& free_list = context_pool()[device];
+		if (!free_list.empty())
+		{
+			nae_ctx* ctx = free_list.back();
+			free_list.pop_back();
+			return ctx;
+		}
+		Setup_timer timer;
+		flight_stats().contexts_created++;
 		nae_ctx* ctx = nullptr;
 		const int rc = nae_ctx_create(device, &ctx);
 		if (rc != NAE_OK)
@@ -83,7 +111,8 @@ namespace processor::gpu
 		~Node()
 		{
 			nae_fiber::this_fiber::local() = outer;
-			nae_ctx_destroy(ctx_);
+			nae_sync(ctx_);
+			context_pool()[device].push_back(ctx_);  // kept for the next run's nodes (destroyed with the process)
 		}
 		nae_ctx* ctx() const { return ctx_; }
 	};
@@ -159,6 +188,7 @@ namespace processor::gpu
 		{
 			if (want > bytes)
 			{
+				Setup_timer timer;
 				if (ptr) { nae_sync(ctx); nae_free(ctx, ptr); ptr = nullptr; }
 				check(nae_malloc(ctx, want + want / 2 + 256, &ptr), "nae_malloc");
 				bytes = want + want / 2 + 256;
@@ -166,5 +196,35 @@ namespace processor::gpu
 			return ptr;
 		}
 		template <typename T> T* as() { return static_cast<T*>(ptr); }
+	};
+
+	// grow-only PAGE-LOCKED host staging of the node that created it.  Audio_frame buffers are pageable (av_frame_get_buffer /
+	// malloc): a hipMemcpyAsync from or to them is staged by the runtime and a download BLOCKS the calling thread until the stream
+	// has reached it — on the one thread all fibers share.  So a node copies the frames of a batch into / out of one pinned buffer
+	// on the CPU (tens of KB: microseconds) and moves the batch with ONE asynchronous copy each way; the fiber then really yields
+	// while the GPU works, and other nodes' batches overlap with it.
+	class Pinned_buffer
+	{
+		nae_ctx* ctx;
+		void* ptr = nullptr;
+		size_t bytes = 0;
+
+	  public:
+
+		Pinned_buffer() : ctx(context()) {}
+		Pinned_buffer(const Pinned_buffer&) = delete;
+		Pinned_buffer& operator=(const Pinned_buffer&) = delete;
+		~Pinned_buffer() { if (ptr) { nae_sync(ctx); nae_free_host(ctx, ptr); } }
+		void* reserve(size_t want)
+		{
+			if (want > bytes)
+			{
+				Setup_timer timer;
+				if (ptr) { nae_sync(ctx); nae_free_host(ctx, ptr); ptr = nullptr; }
+				check(nae_malloc_host(ctx, want + want / 2 + 4096, &ptr), "nae_malloc_host");
+				bytes = want + want / 2 + 4096;
+			}
+			return ptr;
+		}
 	};
 }

@@ -673,7 +673,9 @@ static void bench_host_path(int branches, double seconds, bool print)
 		srcs.push_back(a); srcs.push_back(c);
 		sinks.push_back(sink);
 	}
+	const int devices_before = gpu::flight_stats().devices_used;
 	gpu::flight_stats() = gpu::Flight_stats{};
+	gpu::flight_stats().devices_used = devices_before;
 	// watchdog: a graph that has not finished after 60 s is stopped and the nodes still running are named (never hang the box)
 	std::atomic<bool> finished{false};
 	std::string stuck;
@@ -756,10 +758,12 @@ static void bench_host_path(int branches, double seconds, bool print)
 	std::snprintf(line, sizeof line,
 				  "HOST_PATH {\"graph\": \"audio_volume_adjust -> audio_amix(2) -> pitch_modifier(+3 st), 48 kHz stereo f32, 1152-sample frames\", "
 				  "\"branches\": %d, \"seconds_per_branch\": %.1f, \"wall_s\": %.4f, \"source_frames_per_s\": %.1f, \"sample_frames_per_s\": %.1f, "
-				  "\"real_time_factor\": %.1f, \"gpu_nodes\": %zu, \"devices_used\": %d, \"waits\": %zu, \"waits_per_source_frame\": %.4f, "
+				  "\"real_time_factor\": %.1f, \"setup_s\": %.4f, \"contexts_created\": %zu, \"sample_frames_per_s_without_setup\": %.1f, "
+				  "\"gpu_nodes\": %zu, \"devices_used\": %d, \"waits\": %zu, \"waits_per_source_frame\": %.4f, "
 				  "\"polls_per_wait\": %.2f, \"max_nodes_in_flight\": %d, \"fiber_switches\": %zu, \"cpu_oracle_s\": %.4f, "
 				  "\"cpu_oracle_sample_frames_per_s\": %.1f, \"rel_rms_branch0\": %.3g}",
-				  branches, seconds, wall, in_frames / wall, (double)branches * S / wall, (double)branches * seconds / wall, fs.nodes, fs.devices_used,
+				  branches, seconds, wall, in_frames / wall, (double)branches * S / wall, (double)branches * seconds / wall, fs.setup_seconds,
+				  fs.contexts_created, (double)branches * S / std::max(wall - fs.setup_seconds, 1e-9), fs.nodes, fs.devices_used,
 				  fs.waits, fs.waits / in_frames, fs.waits ? (double)fs.polls / fs.waits : 0.0, fs.max_in_flight, r.context_switches(), cpu,
 				  (double)branches * S / cpu, err);
 	std::cout << line << "\n";
