@@ -302,9 +302,31 @@ def main():
         other = sum(v["avg_ms"] for k, v in kern_report.items() if not k.startswith(("pv_", "resample")))
         out["pitch_node_soundtouch_algorithm"] = {
             "what": "input->mix(2)->pitch->spectrum with the pitch node running the WSOLA + anti-alias FIR + cubic "
-                    "transposer chain restated from SoundTouch 2.3.2 (nae_wsola_block_f32) instead of the phase vocoder",
+                    "transposer chain restated from SoundTouch 2.3.2 (nae_wsola_block_f32) instead of the phase vocoder "
+                    "(st_aa_kernel at rate > 1 is the instantiation with the cubic stage fused behind the filter)",
             "pitch_node_ms": round(w_ms, 3), "kernels_avg_ms": wk, "sequences_per_stream": int(wpl.n_seq),
             "graph_sample_frames_per_s": n_streams * S / ((w_ms + other) * 1e-3)}
+        # what binds the two kernels: vector issue at the measured interval + LDS-array cycles against the kernel's cycles, from the
+        # rocprofv3 --pmc passes of this build with the WSOLA leg in the run (ALT=1 tools/pmc_sq.sh -> profiles/r04_wsola_sq.md)
+        wpath = os.path.join(ROOT, "profiles", "r04_wsola_traffic.json")
+        wdata = json.load(open(wpath)) if os.path.exists(wpath) else {}
+        valu = {}
+        for kname, avg_ms in wk.items():
+            td = wdata.get(kname, {})
+            if not td.get("valu_instr_per_launch") or not td.get("sample_frames"):
+                continue
+            scale = sf / td["sample_frames"]
+            instr = td["valu_instr_per_launch"] * scale
+            cyc = avg_ms * 1e-3 * clock_ghz * 1e9
+            peak_cpi = VALU_MIX_CYCLES_PER_INSTR[td.get("waves_per_simd", 4)]
+            v_cyc, l_cyc = instr / 1024.0 * peak_cpi, td.get("lds_idx_active_per_cu", 0.0) * scale
+            valu[kname] = {"wave_instr_per_launch": instr, "waves_per_simd": td.get("waves_per_simd", 4),
+                           "achieved": round(cyc * 1024 / instr, 3), "peak": peak_cpi, "unit": "cycles per wave-instruction per SIMD (lower is better)",
+                           "frac": round(peak_cpi * instr / 1024 / cyc, 3),
+                           "issue_plus_lds": {"valu_cycles_per_cu": v_cyc, "lds_cycles_per_cu": l_cyc, "kernel_cycles": cyc, "frac": round((v_cyc + l_cyc) / cyc, 3)}}
+        if valu:
+            out["pitch_node_soundtouch_algorithm"]["valu"] = valu
+            out["pitch_node_soundtouch_algorithm"]["valu_source"] = wdata.get("_source")
         ctx.graph4(g)                                        # restore the vocoder result for the parity check below
         ctx.sync()
 

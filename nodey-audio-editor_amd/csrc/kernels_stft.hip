@@ -775,7 +775,7 @@ int nae_launch_spectrum(nae_ctx* ctx, const nae_sig* src, size_t T, int ch, size
     const bool stereo_fast = ch == 2 && src->chan_stride == 1 && src->frame_stride == 2 && src->stream_stride % 4 == 0 &&
                              (reinterpret_cast<uintptr_t>(src->base) & 15) == 0 && !ctx->dbg_spec_generic;
     if (stereo_fast) {
-        const int chunk = spec_pick_chunk((long long)F, (long long)n_streams, ctx->n_cu);
+        const int chunk = ctx->dbg_spec_chunk > 0 ? ctx->dbg_spec_chunk : spec_pick_chunk((long long)F, (long long)n_streams, ctx->n_cu);
         const long long chunks = ((long long)F + chunk - 1) / chunk;
         const long long citems = chunks * (long long)n_streams;
         NAE_KLAUNCH(ctx, "spectrum_stereo_kernel", spectrum_stereo_kernel, dim3((unsigned)((citems + kWaves - 1) / kWaves)), dim3(kThreads),

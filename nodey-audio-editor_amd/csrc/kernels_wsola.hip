@@ -630,10 +630,10 @@ int st_launch_aa_cu(nae_ctx* ctx, const StCfg& c, const StView& in, const long l
         StOut vout = out;
         vout.base += (long long)s0 * out.ss;
         if (c.ch == 2)
-            NAE_KLAUNCH(ctx, "st_aa_cu_kernel", (st_aa_kernel<2, true>), dim3((unsigned)tiles, ns), dim3(256), 0, ctx->stream,
+            NAE_KLAUNCH(ctx, "st_aa_kernel", (st_aa_kernel<2, true>), dim3((unsigned)tiles, ns), dim3(256), 0, ctx->stream,
                         dview(vin, 2), p, dout(vout, 2), cu);
         else
-            NAE_KLAUNCH(ctx, "st_aa_cu_kernel", (st_aa_kernel<1, true>), dim3((unsigned)tiles, ns), dim3(256), 0, ctx->stream,
+            NAE_KLAUNCH(ctx, "st_aa_kernel", (st_aa_kernel<1, true>), dim3((unsigned)tiles, ns), dim3(256), 0, ctx->stream,
                         dview(vin, 1), p, dout(vout, 1), cu);
     }
     return nae_check(ctx, hipGetLastError(), "st_aa_cu_kernel");
@@ -657,10 +657,10 @@ int st_launch_cu_aa(nae_ctx* ctx, const StCfg& c, const StView& in, const long l
         StOut vout = out;
         vout.base += (long long)s0 * out.ss;
         if (c.ch == 2)
-            NAE_KLAUNCH(ctx, "st_cu_aa_kernel", (st_aa_kernel<2, false, true>), dim3(tiles, ns), dim3(256), 0, ctx->stream, dview(vin, 2),
+            NAE_KLAUNCH(ctx, "st_aa_kernel", (st_aa_kernel<2, false, true>), dim3(tiles, ns), dim3(256), 0, ctx->stream, dview(vin, 2),
                         p, dout(vout, 2), cu);
         else
-            NAE_KLAUNCH(ctx, "st_cu_aa_kernel", (st_aa_kernel<1, false, true>), dim3(tiles, ns), dim3(256), 0, ctx->stream, dview(vin, 1),
+            NAE_KLAUNCH(ctx, "st_aa_kernel", (st_aa_kernel<1, false, true>), dim3(tiles, ns), dim3(256), 0, ctx->stream, dview(vin, 1),
                         p, dout(vout, 1), cu);
     }
     return nae_check(ctx, hipGetLastError(), "st_cu_aa_kernel");

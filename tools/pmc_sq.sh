@@ -8,7 +8,9 @@ OUT=$1; shift
 R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $R/$OUT
 cd /tmp; export TMPDIR=/tmp
-BENCH="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-alt --no-pcie --no-host-path --no-kernel-timing"
+# ALT=1: keep the side measurement of the SoundTouch-shaped pitch node in the run (st_td_kernel, st_aa_kernel get counters too)
+NOALT="--no-alt"; [ -n "$ALT" ] && NOALT=""
+BENCH="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline $NOALT --no-pcie --no-host-path --no-kernel-timing"
 rocprofv3 --kernel-trace --stats -d $R/$OUT/p0 -o trace --output-format csv -- $BENCH "$@" > $R/$OUT/p0.log 2>&1
 echo "stats pass done"
 i=0

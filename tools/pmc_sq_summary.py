@@ -23,7 +23,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # kernel symbol -> the launch label bench.py reports it under
 LABEL = {}      # bench.py labels its launches with the names rocprofv3 prints
-WAVES_PER_SIMD = {"pv_pipe_kernel": 8, "spectrum_stereo_kernel": 4, "mix_resample_tile_kernel": 5}
+WAVES_PER_SIMD = {"pv_pipe_kernel": 8, "spectrum_stereo_kernel": 4, "mix_resample_tile_kernel": 5, "st_td_kernel": 4, "st_aa_kernel": 8}
 
 
 def compiler_resources():
@@ -33,7 +33,7 @@ def compiler_resources():
     import subprocess
     res = {}
     src_dir = os.path.join(ROOT, "nodey-audio-editor_amd", "csrc")
-    for tu in ("kernels_stft.hip", "kernels_pvpipe.hip"):
+    for tu in ("kernels_stft.hip", "kernels_pvpipe.hip", "kernels_wsola.hip"):
         r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
                             "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(src_dir, tu), "-o", "/dev/null"], capture_output=True, text=True)
         cur = None
@@ -63,7 +63,9 @@ def norm(name):
 
 def main():
     d, tag = sys.argv[1], sys.argv[2]
-    sf = int(sys.argv[3]) if len(sys.argv) > 3 else 1024 * 480000
+    no_traffic = "--no-traffic" in sys.argv           # a side run (e.g. the WSOLA leg): profiles/traffic.json keeps the headline run's numbers
+    args = [a for a in sys.argv[3:] if a != "--no-traffic"]
+    sf = int(args[0]) if args else 1024 * 480000
     prof = os.path.join(ROOT, "profiles")
     vals = collections.defaultdict(lambda: collections.defaultdict(list))
     meta = {}
@@ -121,7 +123,10 @@ def main():
         lines.append(f"| {k} | {dur.get(k, float('nan')):.3f} | {med[k]['FETCH_SIZE']:.0f} | {rd:.4g} | {med[k].get('WRITE_SIZE', 0):.0f} | {rd + wr:.4g} | {(rd + wr) / sf:.2f} | "
                      f"{vg(k)} |")
     open(os.path.join(prof, f"{tag}_pmc.md"), "w").write("\n".join(lines) + "\n")
-    json.dump(traffic, open(os.path.join(prof, "traffic.json"), "w"), indent=1)
+    if not no_traffic:
+        json.dump(traffic, open(os.path.join(prof, "traffic.json"), "w"), indent=1)
+    else:
+        json.dump(traffic, open(os.path.join(prof, f"{tag}_traffic.json"), "w"), indent=1)
     print("\n".join(out[-len(keep) - 3:]))
     print("\n".join(lines))
 
