@@ -302,7 +302,7 @@ __global__ void pv_scan_kernel(uint32_t* __restrict__ sums, long long n_sc, int 
 }
 
 // rate transposer: out[j] = sum_i tab(phase)[i] * v[idx - 7 + i],  pos = j * step (Q32.32)
-struct RsParams { unsigned long long step_q32; long long src_len; long long out_len; int ch; long long j_begin; int rot; };
+struct RsParams { unsigned long long step_q32; long long src_len; long long out_len; int ch; long long j_begin; int rot; int tile_out; };
 
 // LDS slot of coefficient row ph in the tiled kernels.  Neighbouring outputs advance the phase by a fixed amount (24.2
 // rows at the default +3 semitones), and with rows stored in order every other lane of a 16-lane read group lands on the
@@ -351,8 +351,11 @@ __global__ __launch_bounds__(256) void resample_kernel(SigViewD src, RsParams p,
 // tiled rate transposer: a 256-thread workgroup produces kRsOut consecutive output frames of one stream; the
 // source span it needs (kRsOut*rho + 16 samples per channel) is staged once into LDS with 16-byte loads, the
 // 16 taps are read from LDS, and interleaved stereo output leaves as one 8-byte store per frame.
-constexpr int kRsOut = 512;                      // output frames per workgroup.  Measured: 256 -> 3.6 ms, 512 -> 3.07, 1024 -> 3.4
-                                                 // (C5 mix+transposer; LDS per workgroup sets the occupancy)
+constexpr int kRsOut = 512;                      // output frames per workgroup when the wider tile does not fit.  Round 1: 256 -> 3.6 ms, 512 -> 3.07,
+                                                 // 1024 -> 3.4 (C5 mix+transposer; LDS per workgroup sets the occupancy)
+constexpr int kRsOutWide = 768;                  // round 4 (16-byte tap reads): 384 -> 2.58 ms, 512 -> 2.44, 768 -> 2.35, 1024 -> 2.70 on one box — three
+                                                 // longer-lived workgroups per CU beat five; used while 4 streams of 768 rho + 28 frames fit the
+                                                 // 1536-frame staging rows (rho <= 1.96), see rs_pick_tile
 constexpr int kRsRow = 20;                       // LDS row stride of the coefficient table (16 taps + 4 pad): a 64-B
                                                  // stride maps every row to one of 4 bank slots (4-way conflicts on b128)
 constexpr int kRsMaxSpan = 4096 + 32;            // staged source samples per channel (rho <= 4)
@@ -485,8 +488,8 @@ __global__ __launch_bounds__(kRsThreads) void resample_tile_kernel(SigViewD src,
     float* stage = stab + (NAE_RS_PHASES + 1) * kRsRow;                        // stereo: [NS][span_alloc][2]; else [ch][span_alloc]
     rs_fill_table(stab, tab, p.rot);
     const long long s0 = (long long)blockIdx.y * NS;
-    const long long j0 = p.j_begin + (long long)blockIdx.x * kRsOut;
-    long long j1 = j0 + kRsOut;
+    const long long j0 = p.j_begin + (long long)blockIdx.x * p.tile_out;
+    long long j1 = j0 + p.tile_out;
     if (j1 > p.out_len) j1 = p.out_len;
     // source window [m_lo, m_hi) of this tile, m_lo rounded down to a multiple of 4 samples
     const unsigned long long lo0 = (unsigned long long)j0 * p.step_q32, hi0 = __umul64hi((unsigned long long)j0, p.step_q32);
@@ -591,8 +594,8 @@ __global__ __launch_bounds__(kRsThreads) void mix_resample_tile_kernel(MixFuseD 
     float* stab = reinterpret_cast<float*>(rs_smem);
     float* stage = stab + (NAE_RS_PHASES + 1) * kRsRow;
     const long long s0 = (long long)blockIdx.y * NS;
-    const long long j0 = (long long)blockIdx.x * kRsOut;
-    long long j1 = j0 + kRsOut;
+    const long long j0 = (long long)blockIdx.x * p.tile_out;
+    long long j1 = j0 + p.tile_out;
     const bool last = j1 >= p.out_len;
     if (last) j1 = p.out_len;
     auto idx_of = [&](long long j) {
@@ -752,6 +755,15 @@ static int spec_pick_chunk(long long frames, long long n_streams, int n_cu)
     return (int)best_chunk;
 }
 
+// output frames per transposer workgroup and the staging row it needs (frames per channel, a multiple of 4)
+static int rs_pick_tile(double rho, long long* span_need)
+{
+    auto need = [&](int tile) { return (long long)(tile * rho) + NAE_RS_TAPS + 8 + 4; };   // + 4: the aligned 16-byte tap reads look one pair of frames further
+    const int tile = need(kRsOutWide) <= 1536 ? kRsOutWide : kRsOut;
+    *span_need = need(tile);
+    return tile;
+}
+
 static inline SigViewD to_view(const nae_sig* s)
 {
     return SigViewD{static_cast<const float*>(s->base), (long long)s->stream_stride, (long long)s->chan_stride,
@@ -901,17 +913,18 @@ int nae_launch_resample(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig*
                         size_t n_streams, const float* d_tab, const nae_sig* out, size_t j_begin, size_t j_end)
 {
     if (j_end <= j_begin || n_streams == 0) return NAE_OK;
-    RsParams p{pl->step_q32, (long long)src_len, (long long)j_end, ch, (long long)j_begin, rs_pick_rot(pl->step_q32)};
     const size_t count = j_end - j_begin;
     // tiled kernel while one tile's source span fits the staging buffer (rho <= 4), else the direct kernel
     const double rho = (double)pl->step_q32 / 4294967296.0;
-    const long long span_need = (long long)(kRsOut * rho) + NAE_RS_TAPS + 8 + 4;      // + 4: the aligned 16-byte tap reads look one pair of frames further
+    long long span_need = 0;
+    const int tile_out = rs_pick_tile(rho, &span_need);
+    RsParams p{pl->step_q32, (long long)src_len, (long long)j_end, ch, (long long)j_begin, rs_pick_rot(pl->step_q32), tile_out};
     const bool tiled = span_need <= kRsMaxSpan && !ctx->dbg_rs_direct;
     const int span_alloc = (int)((span_need + 3) & ~3ll);
     // stereo batches: 4 streams per workgroup share the per-output coefficients (if their staging fits LDS)
     const int group = (tiled && ch == 2 && n_streams >= 4 && span_alloc <= 1536 && !ctx->dbg_rs_single) ? 4 : 1;
     const size_t lds = ((NAE_RS_PHASES + 1) * kRsRow + (size_t)ch * span_alloc * group) * sizeof(float);
-    const unsigned gx = tiled ? (unsigned)((count + kRsOut - 1) / kRsOut) : (unsigned)((count + 255) / 256);
+    const unsigned gx = tiled ? (unsigned)((count + tile_out - 1) / tile_out) : (unsigned)((count + 255) / 256);
     // blockIdx.y is limited to 65535
     const size_t per_launch = (size_t)65535 * group;
     for (size_t s0 = 0; s0 < n_streams; s0 += per_launch) {
@@ -944,7 +957,8 @@ int nae_launch_mix_resample(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_
                             const nae_sig* mix_out, size_t S, size_t n_streams, const float* d_tab, const nae_sig* out)
 {
     const double rho = (double)pl->step_q32 / 4294967296.0;
-    const long long span_need = (long long)(kRsOut * rho) + NAE_RS_TAPS + 8 + 4;
+    long long span_need = 0;
+    const int tile_out = rs_pick_tile(rho, &span_need);
     const int span_alloc = (int)((span_need + 3) & ~3ll);
     auto inter16 = [](const nae_sig* v) {
         return v->chan_stride == 1 && v->frame_stride == 2 && (reinterpret_cast<uintptr_t>(v->base) & 15) == 0 && (v->stream_stride & 3) == 0;
@@ -956,9 +970,9 @@ int nae_launch_mix_resample(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_
     if (ctx->dbg_no_mix_fuse || !inter16(a) || !inter16(b) || !mix_ok || span_need > kRsMaxSpan || span_alloc > 1536 || n_streams == 0 ||
         pl->mid_len == 0 || S == 0)
         return 1;
-    RsParams p{pl->step_q32, (long long)S, (long long)pl->mid_len, 2, 0, rs_pick_rot(pl->step_q32)};
+    RsParams p{pl->step_q32, (long long)S, (long long)pl->mid_len, 2, 0, rs_pick_rot(pl->step_q32), tile_out};
     const size_t lds = ((NAE_RS_PHASES + 1) * kRsRow + (size_t)2 * span_alloc * 4) * sizeof(float);
-    const unsigned gx = (unsigned)((pl->mid_len + kRsOut - 1) / kRsOut);
+    const unsigned gx = (unsigned)((pl->mid_len + tile_out - 1) / tile_out);
     const size_t per_launch = (size_t)65535 * 4;
     for (size_t s0 = 0; s0 < n_streams; s0 += per_launch) {
         const size_t ns = (n_streams - s0 < per_launch) ? n_streams - s0 : per_launch;

@@ -1,4 +1,5 @@
-"""CPU: the ONE row of the path that can be pinned against the reference's own code.
+"""CPU: what of the path can be pinned against the reference's own code: K1 whole (the function), K3 / K4 / K5 by their arithmetic
+statements (second half of this file).
 
 `change_volume<T>` (/root/reference/src/processor/audio-vol.cpp:75-100) needs only <algorithm> / <cstdint>, so `make -C oracle ref`
 compiles it from where it lies into oracle/_ref/ (git-ignored; built by __graft_entry__.build() when /root/reference is present; the
@@ -10,8 +11,9 @@ reference (audio-vol.cpp:98, no clamp): the g++ build wraps like `cvttss2si` + m
 the GPU kernel do — while clang's vectorised body SATURATES int16 (`packssdw`) and its scalar tail wraps; the last
 test pins both facts, so "bit-exact int-PCM gain" is a statement about in-range products plus the g++ build's choice beyond them.
 
-Every other loop of the path sits inside a process_payload body between FFmpeg / Boost calls and cannot be compiled without
-stand-ins for headers this image lacks, so K2-K6 stay pinned by the numpy restatement only."""
+Every other loop of the path sits inside a process_payload body between FFmpeg / Boost calls: as FUNCTIONS they cannot be compiled
+without stand-ins for headers this image lacks (DESIGN.md §5).  For K3 / K4 / K5 the arithmetic statements alone are compiled (below);
+K2 (pure data movement) and K6 (its statements read AVFrame fields) stay pinned by the numpy restatement only."""
 import ctypes as C
 import os
 import subprocess
@@ -134,3 +136,71 @@ def test_out_of_range_integer_products(dtype):
         assert np.array_equal(c[m], o[m]), (dtype, v)
         if dtype == np.int16 and v >= 2.0:
             assert not np.array_equal(c, o)                      # compilers disagree where the reference leaves the result undefined
+
+
+# ---------------------------------------------------------------------------------------------- K3 / K4 / K5: arithmetic statements
+# oracle/ref_mix_tu.sh streams the arithmetic STATEMENTS of three more loops from the reference into wrapper loops (the loop headers
+# and the variable declarations are the builder's, repeating the reference's types; no FFmpeg / Boost header is imitated):
+#   K3 audio-amix.cpp:298-306, K4 audio-bimix.cpp:310-311,315-316, K5 audio-bimix.cpp:627.
+# So for K3-K5 the pin covers what the reference computes per sample and in which order, not the frame plumbing around it.
+MIX_BUILDS = {"g++": "libref_mix.so", "clang": "libref_mix_clang.so"}
+
+
+@pytest.fixture(scope="module", params=["g++", "clang"])
+def refmix(request):
+    so = os.path.join(REF_DIR, MIX_BUILDS[request.param])
+    if not os.path.exists(so):
+        if not os.path.exists(REF_SRC):
+            pytest.skip("oracle/_ref was not built and /root/reference is not on this box")
+        r = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "ref"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+    L = C.CDLL(so)
+    L.ref_amix_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    L.ref_bimix_f32.argtypes = [C.c_void_p] * 4 + [C.c_float, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.ref_bimix2_downmix_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    for f in (L.ref_amix_f32, L.ref_bimix_f32, L.ref_bimix2_downmix_f32):
+        f.restype = None
+    return L
+
+
+def special(n, seed):
+    """uniform noise with the awkward values in front: zeros of both signs, subnormals, huge, Inf, NaN"""
+    x = orc.fill_uniform(n, seed).copy()
+    edge = np.array([0.0, -0.0, 1e-40, -1e-40, 1.1754944e-38, 3.4e38, -3.4e38, np.inf, -np.inf, np.nan, 1.0, -1.0], np.float32)
+    x[:min(n, edge.size)] = edge[:min(n, edge.size)]
+    return x
+
+
+@pytest.mark.parametrize("n_in", [1, 2, 3, 16])
+def test_k3_mix_statements_of_the_reference(refmix, n_in):
+    S = 4099
+    rng = np.random.default_rng(n_in)
+    inL = [special(S, 10 * n_in + i) if i == 0 else orc.fill_uniform(S, 10 * n_in + i) for i in range(n_in)]
+    inR = [orc.fill_uniform(S, 100 + 10 * n_in + i) for i in range(n_in)]
+    vol = rng.uniform(0, 1, n_in).astype(np.float32)
+    oL, oR = orc.amix(inL, inR, vol)
+    # datas[i] = {left plane, right plane} as uint8_t** (what swr_convert fills, audio-amix.cpp:251-269)
+    pairs = [(C.c_void_p * 2)(inL[i].ctypes.data, inR[i].ctypes.data) for i in range(n_in)]
+    datas = (C.c_void_p * n_in)(*[C.addressof(p) for p in pairs])
+    rL, rR = np.empty(S, np.float32), np.empty(S, np.float32)
+    refmix.ref_amix_f32(datas, vol.ctypes.data, n_in, rL.ctypes.data, rR.ctypes.data, S)
+    assert same_bits(rL, oL) and same_bits(rR, oR)
+
+
+@pytest.mark.parametrize("bias", [-1.0, -0.3, 0.0, 0.25, 1.0])
+def test_k4_bimix_statements_of_the_reference(refmix, bias):
+    S = 4099
+    a = [special(S, 21), orc.fill_uniform(S, 22), orc.fill_uniform(S, 23), special(S, 24)]
+    oL, oR = orc.bimix(*a, bias)
+    rL, rR = np.empty(S, np.float32), np.empty(S, np.float32)
+    refmix.ref_bimix_f32(*[x.ctypes.data for x in a], C.c_float(bias), rL.ctypes.data, rR.ctypes.data, S)
+    assert same_bits(rL, oL) and same_bits(rR, oR)
+
+
+def test_k5_downmix_statement_of_the_reference(refmix):
+    S = 4099
+    l, r = special(S, 31), special(S, 32)[::-1].copy()
+    m = orc.bimix2_downmix(l, r)
+    ref = np.empty(S, np.float32)
+    refmix.ref_bimix2_downmix_f32(l.ctypes.data, r.ctypes.data, ref.ctypes.data, S)
+    assert same_bits(ref, m)          # incl. the subnormal halving: (l + r) * 0.5 is a DOUBLE product rounded once
