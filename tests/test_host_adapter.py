@@ -34,3 +34,23 @@ def test_host_mirror_scheduler_registry_json():
 def test_host_mirror_gpu_graphs():
     """GPU: volume / amix / pitch->spectrum with fan-out / velocity / bimix_v2 graphs vs the oracle; error capture"""
     run("gpu")
+
+
+@pytest.mark.gpu
+def test_host_path_benchmark_runs_and_overlaps_nodes():
+    """`selftest bench`: volume -> amix(2) -> pitch on 1152-sample frames, one branch and 16 branches in one fiber runner; branch 0 is
+    checked against the oracle inside the program.  Here: it finishes by itself (its watchdog names a node that spins), every node
+    waits for its own stream (several nodes in flight at once) and the batches make waits rare."""
+    import json
+    build()
+    r = subprocess.run([os.path.join(HOST_TEST, "selftest"), "bench", "4"], capture_output=True, text=True, timeout=280)
+    print(r.stdout[-3000:], r.stderr[-1000:])
+    assert r.returncode == 0 and "SELFTEST OK bench" in r.stdout, r.stdout[-2000:]
+    runs = [json.loads(line[len("HOST_PATH "):]) for line in r.stdout.splitlines() if line.startswith("HOST_PATH ")]
+    assert [x["branches"] for x in runs] == [1, 16]
+    for x in runs:
+        assert x["rel_rms_branch0"] <= 1e-4                    # K7 tolerance of north_star
+        assert x["waits_per_source_frame"] <= 0.5               # frames are batched behind shared waits
+        assert x["real_time_factor"] > 20
+    assert runs[0]["max_nodes_in_flight"] >= 2 and runs[1]["max_nodes_in_flight"] >= 2
+    assert runs[1]["gpu_nodes"] == 48
