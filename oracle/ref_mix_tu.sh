@@ -5,6 +5,8 @@
 #   K3  audio-amix.cpp:298-306    the body of the sample loop of the N-input mixer (accumulators, input loop, two stores)
 #   K4  audio-bimix.cpp:310-311   bias_minus / bias_plus;  :315-316  the two output statements of the channel mixer
 #   K5  audio-bimix.cpp:627       the mono downmix statement of the channel mixer v2
+#   K5  audio-bimix.cpp:799-803 and :836-850   the interleave loops of the channel mixer v2 WITH their headers (they are bounded by
+#       plain size_t counts): the single-sided frame and the unaligned + aligned frame
 # What is NOT the reference's: the loop headers (the reference bounds them by AVFrame::nb_samples / a C++23 views::zip, neither of
 # which exists in this image — the statements themselves use only float pointers, std::vector and scalars) and the declarations of
 # the variables the statements name, which repeat the reference's own types (audio-amix.cpp:244 `std::vector<uint8_t**> datas`,
@@ -21,6 +23,9 @@ sed -n '306p' $AMIX | grep -q 'out_right\[j\] = temp_r;'
 sed -n '310p' $BIMIX | grep -q 'const float bias_minus = (1 - bias);'
 sed -n '315p' $BIMIX | grep -q 'out_left\[i\] = (float_data_ll\[i\] / 2 + float_data_lr\[i\] / 2) \* bias_minus;'
 sed -n '627p' $BIMIX | grep -q 'dst = (left + right) \* 0.5;'
+sed -n '799p' $BIMIX | grep -q 'for (size_t i = 0; i < eariler_stream.front().samples.size(); i++)'
+sed -n '837p' $BIMIX | grep -q 'for (size_t i = 0; i < unaligned_samples; i++)'
+sed -n '850p' $BIMIX | grep -q '^[[:space:]]*}$'
 cat <<'PRE'
 #include <cstddef>
 #include <cstdint>
@@ -64,3 +69,36 @@ cat <<'POST'
     for (size_t k = 0; k < n; k++) mono[k] = samples[k];
 }
 POST
+cat <<'MID4'
+#include <list>
+namespace
+{
+    struct Frame { std::vector<float> samples; };      // audio-bimix.cpp:513-516 (the loops touch `samples` only)
+}
+// later == nullptr: the single-sided frame (:797-803); else the unaligned + aligned frame (:833-850).  dst holds 2 * (unaligned + aligned) floats
+extern "C" void ref_bimix2_interleave_f32(float* dst, const float* earlier, size_t n_earlier, const float* later, size_t n_later,
+                                          size_t unaligned_samples, size_t aligned_samples, int earlier_channel)
+{
+    std::list<Frame> eariler_stream(1), later_stream(1);                 // :528 std::list<Frame> frames_l, frames_r
+    eariler_stream.front().samples.assign(earlier, earlier + n_earlier);
+    if (later) later_stream.front().samples.assign(later, later + n_later);
+    const size_t eariler_offset = earlier_channel ? 1 : 0;               // :783-784
+    const size_t later_offset = earlier_channel ? 0 : 1;
+    std::vector<float> frame_samples;                                    // :534
+    if (!later)
+    {
+        frame_samples.resize(eariler_stream.front().samples.size() * 2);
+MID4
+sed -n '799,803p' $BIMIX
+cat <<'MID5'
+    }
+    else
+    {
+        frame_samples.resize((unaligned_samples + aligned_samples) * 2);
+MID5
+sed -n '836,850p' $BIMIX
+cat <<'POST2'
+    }
+    for (size_t k = 0; k < frame_samples.size(); k++) dst[k] = frame_samples[k];
+}
+POST2

@@ -204,3 +204,20 @@ def test_k5_downmix_statement_of_the_reference(refmix):
     ref = np.empty(S, np.float32)
     refmix.ref_bimix2_downmix_f32(l.ctypes.data, r.ctypes.data, ref.ctypes.data, S)
     assert same_bits(ref, m)          # incl. the subnormal halving: (l + r) * 0.5 is a DOUBLE product rounded once
+
+
+@pytest.mark.parametrize("earlier_channel", [0, 1])
+def test_k5_interleave_loops_of_the_reference(refmix, earlier_channel):
+    """audio-bimix.cpp:799-803 (single-sided frame) and :836-850 (unaligned + aligned frame), loops and headers as they stand"""
+    refmix.ref_bimix2_interleave_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int]
+    refmix.ref_bimix2_interleave_f32.restype = None
+    e, l = special(3000, 41), special(2500, 42)
+    for unaligned, aligned in ((0, 2500), (123, 2500), (500, 2000), (2999, 1), (3000, 0), (0, 0)):
+        want = orc.bimix2_interleave(e, l, unaligned, aligned, earlier_channel)
+        got = np.empty(2 * (unaligned + aligned), np.float32)
+        refmix.ref_bimix2_interleave_f32(got.ctypes.data, e.ctypes.data, e.size, l.ctypes.data, l.size, unaligned, aligned, earlier_channel)
+        assert same_bits(got, want), (unaligned, aligned)
+    want = orc.bimix2_interleave(e, None, e.size, 0, earlier_channel)
+    got = np.empty(2 * e.size, np.float32)
+    refmix.ref_bimix2_interleave_f32(got.ctypes.data, e.ctypes.data, e.size, None, 0, 0, 0, earlier_channel)
+    assert same_bits(got, want)
