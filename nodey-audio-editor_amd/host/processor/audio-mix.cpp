@@ -423,6 +423,7 @@ namespace processor
 		Gpu_swr resampler_l, resampler_r;
 		nae_ctx* ctx = gpu::context();
 		gpu::Device_buffer d_in, d_out;
+		gpu::Pinned_buffer h_out;
 
 		// batched like Audio_amix: the rounds that the waiting frames allow are planned, queued and waited for once
 		constexpr size_t max_batch = 16;
@@ -493,12 +494,19 @@ namespace processor
 				const int convert_count_r = resampler_r.convert_queued(frame_r, in + 2 * r.plane, in + 3 * r.plane, r.S);
 				float* o = dout + r.out_off;
 				gpu::check(nae_bimix_f32(ctx, in, in + r.plane, in + 2 * r.plane, in + 3 * r.plane, bias, o, o + r.plane, r.S), "nae_bimix_f32");
-				gpu::check(nae_memcpy_d2h(ctx, r.out->data()->data[0], o, r.S * sizeof(float)), "d2h");
-				gpu::check(nae_memcpy_d2h(ctx, r.out->data()->data[1], o + r.plane, r.S * sizeof(float)), "d2h");
 				done++;
 				if (convert_count_r == 0 && convert_count_l == 0) { finished = true; break; }  // :327
 			}
+			// all rounds come down as ONE asynchronous copy into page-locked staging (a copy into the pageable frames would block
+			// this thread until the stream has reached it)
+			float* hout = static_cast<float*>(h_out.reserve(out_floats * sizeof(float)));
+			if (done) gpu::check(nae_memcpy_d2h(ctx, hout, dout, (rounds[done - 1].out_off + 2 * rounds[done - 1].plane) * sizeof(float)), "d2h");
 			gpu::wait(stop_token);
+			for (size_t k = 0; k < done; k++)
+			{
+				std::memcpy(rounds[k].out->data()->data[0], hout + rounds[k].out_off, (size_t)rounds[k].S * sizeof(float));
+				std::memcpy(rounds[k].out->data()->data[1], hout + rounds[k].out_off + rounds[k].plane, (size_t)rounds[k].S * sizeof(float));
+			}
 			batch_stats.rounds += done;
 			batch_stats.waits++;
 			buf_l.erase(buf_l.begin(), buf_l.begin() + std::min(done, buf_l.size()));
@@ -572,6 +580,7 @@ namespace processor
 		// take the waiting frames off an input: convert, advance the side's clock by what the converter delivered (:594-618: a
 		// block is stamped with the time BEHIND it), mix down to mono on the GPU and queue the blocks
 		gpu::Device_buffer d_l, d_r, d_m;
+		gpu::Pinned_buffer h_m, h_frames;
 		auto intake = [&](Side& sd)
 		{
 			if (sd.ended) return;
@@ -599,8 +608,10 @@ namespace processor
 			float* dl = static_cast<float*>(d_l.reserve(room_total * sizeof(float)));
 			float* dr = static_cast<float*>(d_r.reserve(room_total * sizeof(float)));
 			float* dm = static_cast<float*>(d_m.reserve(room_total * sizeof(float)));
+			float* hm = static_cast<float*>(h_m.reserve(room_total * sizeof(float)));  // page-locked: the downloads do not block this thread
 			std::vector<Pending> staged;
-			staged.reserve(frames.size());  // the downloads below write into the blocks' vectors: they must not move
+			std::vector<size_t> staged_off;
+			staged.reserve(frames.size());
 			size_t off = 0;
 			for (const auto& f : frames)
 			{
@@ -621,18 +632,20 @@ namespace processor
 					block.mono.resize(n);
 					gpu::check(nae_bimix2_downmix_f32(ctx, dl + off, dr + off, dm + off, n), "nae_bimix2_downmix_f32");
 					staged.emplace_back(std::move(block));
-					gpu::check(nae_memcpy_d2h(ctx, staged.back().mono.data(), dm + off, n * sizeof(float)), "d2h");
+					staged_off.push_back(off);
+					gpu::check(nae_memcpy_d2h(ctx, hm + off, dm + off, n * sizeof(float)), "d2h");
 				}
 				off += (room + 3) / 4 * 4;
 			}
 			gpu::wait(stop_token);  // the frames (upload sources) are released only now
+			for (size_t k = 0; k < staged.size(); k++) std::memcpy(staged[k].mono.data(), hm + staged_off[k], staged[k].mono.size() * sizeof(float));
 			batch_stats.rounds += frames.size();
 			batch_stats.waits++;
 			for (Pending& block : staged) sd.queue.emplace_back(std::move(block));
 		};
 
 		// output frames queued on the GPU since the last flush; the blocks their uploads read from stay alive in `retired`
-		struct Job { std::shared_ptr<Audio_frame> frame; };
+		struct Job { std::shared_ptr<Audio_frame> frame; size_t host_off = 0, floats = 0; };
 		std::vector<Job> jobs;
 		std::vector<Pending> retired;
 		size_t job_floats_a = 0, job_floats_b = 0, job_floats_out = 0, round_cap = 0;
@@ -642,7 +655,11 @@ namespace processor
 			gpu::wait(stop_token);
 			batch_stats.rounds += jobs.size();
 			batch_stats.waits++;
-			for (Job& j : jobs) push_to_all(output_stream, j.frame, stop_token);
+			for (Job& j : jobs)
+			{
+				if (j.floats) std::memcpy(j.frame->data()->data[0], static_cast<float*>(h_frames.reserve(0)) + j.host_off, j.floats * sizeof(float));
+				push_to_all(output_stream, j.frame, stop_token);
+			}
 			jobs.clear();
 			retired.clear();
 			job_floats_a = job_floats_b = job_floats_out = 0;
@@ -656,6 +673,7 @@ namespace processor
 			d_a.reserve(pending * sizeof(float));
 			d_b.reserve(pending * sizeof(float));
 			d_out.reserve(2 * pending * sizeof(float) + 64);
+			h_frames.reserve(2 * pending * sizeof(float) + 64);
 			round_cap = pending;
 		};
 
@@ -680,12 +698,14 @@ namespace processor
 				gpu::check(nae_memcpy_h2d(ctx, da, first_side, n * sizeof(float)), "h2d");
 				if (both) gpu::check(nae_memcpy_h2d(ctx, db, other_side, both * sizeof(float)), "h2d");
 				gpu::check(nae_bimix2_interleave_f32(ctx, dd, da, both ? db : nullptr, solo, both, first), "nae_bimix2_interleave_f32");
-				gpu::check(nae_memcpy_d2h(ctx, data->data[0], dd, 2 * n * sizeof(float)), "d2h");
+				gpu::check(nae_memcpy_d2h(ctx, static_cast<float*>(h_frames.reserve(0)) + job_floats_out, dd, 2 * n * sizeof(float)), "d2h");
+				jobs.push_back({frame, job_floats_out, 2 * n});
 				job_floats_a += (n + 3) / 4 * 4;
 				job_floats_b += (both + 3) / 4 * 4;
 				job_floats_out += (2 * n + 3) / 4 * 4;
 			}
-			jobs.push_back({frame});
+			else
+				jobs.push_back({frame, 0, 0});
 		};
 		auto emit_alone = [&](int which)
 		{
