@@ -13,9 +13,13 @@
 # include/processor/audio-amix.hpp:37 `std::vector<float> volumes`, audio-bimix.cpp:303-308 float pointers, :515,533 std::vector<float>).
 # No stand-in for any FFmpeg / Boost / JsonCpp header is written.  So these pins cover the arithmetic and its order of
 # operations as the reference's compiler sees them, not the frame plumbing around them.
+#   K6  audio-velocity.cpp:186 and :207   the two conversion LAMBDAS of extract_samples_interleaved (packed S16 and packed S32: each
+#       is a whole lambda expression on one line); the planar branches (:196-197, :217-218) read AVFrame fields inside the same
+#       statement and are not compiled
 REF=${1:-/root/reference}
 AMIX=$REF/src/processor/audio-amix.cpp
 BIMIX=$REF/src/processor/audio-bimix.cpp
+VELO=$REF/src/processor/audio-velocity.cpp
 set -e
 # the cited lines are still where SURVEY.md says
 sed -n '298p' $AMIX | grep -q 'float temp_l = 0.0f;'
@@ -26,6 +30,8 @@ sed -n '627p' $BIMIX | grep -q 'dst = (left + right) \* 0.5;'
 sed -n '799p' $BIMIX | grep -q 'for (size_t i = 0; i < eariler_stream.front().samples.size(); i++)'
 sed -n '837p' $BIMIX | grep -q 'for (size_t i = 0; i < unaligned_samples; i++)'
 sed -n '850p' $BIMIX | grep -q '^[[:space:]]*}$'
+sed -n '186p' $VELO | grep -q '\[\](int16_t sample) { return static_cast<float>(sample) / 32768.0f; }'
+sed -n '207p' $VELO | grep -q '\[\](int32_t sample) { return static_cast<float>(sample) / 2147483648.0f; }'
 cat <<'PRE'
 #include <cstddef>
 #include <cstdint>
@@ -101,4 +107,22 @@ cat <<'POST2'
     }
     for (size_t k = 0; k < frame_samples.size(); k++) dst[k] = frame_samples[k];
 }
+extern "C" void ref_k6_s16_packed(const int16_t* in, float* out, size_t n)
+{
+    auto convert =
 POST2
+sed -n '186p' $VELO
+cat <<'MID6'
+    ;
+    for (size_t k = 0; k < n; k++) out[k] = convert(in[k]);
+}
+extern "C" void ref_k6_s32_packed(const int32_t* in, float* out, size_t n)
+{
+    auto convert =
+MID6
+sed -n '207p' $VELO
+cat <<'POST3'
+    ;
+    for (size_t k = 0; k < n; k++) out[k] = convert(in[k]);
+}
+POST3

@@ -13,7 +13,8 @@ test pins both facts, so "bit-exact int-PCM gain" is a statement about in-range 
 
 Every other loop of the path sits inside a process_payload body between FFmpeg / Boost calls: as FUNCTIONS they cannot be compiled
 without stand-ins for headers this image lacks (DESIGN.md §5).  For K3 / K4 / K5 the arithmetic statements alone are compiled (below);
-K2 (pure data movement) and K6 (its statements read AVFrame fields) stay pinned by the numpy restatement only."""
+K6's two packed-integer conversions are one-line lambdas and are compiled as they stand (last test); K2 (pure data movement) and K6's
+planar branches (their statements read AVFrame fields) stay pinned by the numpy restatement only."""
 import ctypes as C
 import os
 import subprocess
@@ -221,3 +222,25 @@ def test_k5_interleave_loops_of_the_reference(refmix, earlier_channel):
     got = np.empty(2 * e.size, np.float32)
     refmix.ref_bimix2_interleave_f32(got.ctypes.data, e.ctypes.data, e.size, None, 0, 0, 0, earlier_channel)
     assert same_bits(got, want)
+
+
+@pytest.mark.parametrize("dtype,fn,fmt", [(np.int16, "ref_k6_s16_packed", orc.FMT_S16), (np.int32, "ref_k6_s32_packed", orc.FMT_S32)])
+def test_k6_packed_integer_lambdas_of_the_reference(refmix, dtype, fn, fmt):
+    """audio-velocity.cpp:186 (S16 / 32768.0f) and :207 (S32 / 2147483648.0f): the lambdas as they stand, over every int16 value and
+    over random + extreme int32 values"""
+    f = getattr(refmix, fn)
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    f.restype = None
+    info = np.iinfo(dtype)
+    if dtype == np.int16:
+        x = np.arange(info.min, info.max + 1, dtype=np.int64).astype(dtype)
+    else:
+        rng = np.random.default_rng(6)
+        x = rng.integers(info.min, info.max, 1 << 16, dtype=np.int64, endpoint=True).astype(dtype)
+        x[:6] = [info.min, info.max, 0, -1, 1, info.min + 1]
+    if x.size % 2:
+        x = x[:-1]
+    got = np.empty(x.size, np.float32)
+    f(x.ctypes.data, got.ctypes.data, x.size)
+    rc, want = orc.to_f32_interleaved(fmt, [x], x.size // 2, 2)      # packed stereo: one plane of S * 2 samples
+    assert rc == 0 and same_bits(got, want)
