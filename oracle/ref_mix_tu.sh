@@ -13,6 +13,7 @@
 # include/processor/audio-amix.hpp:37 `std::vector<float> volumes`, audio-bimix.cpp:303-308 float pointers, :515,533 std::vector<float>).
 # No stand-in for any FFmpeg / Boost / JsonCpp header is written.  So these pins cover the arithmetic and its order of
 # operations as the reference's compiler sees them, not the frame plumbing around them.
+#   K3  audio-amix.cpp:379-387    the renormalisation of the unlocked mixer weights (loops with their headers: plain ints and vectors)
 #   K6  audio-velocity.cpp:186 and :207   the two conversion LAMBDAS of extract_samples_interleaved (packed S16 and packed S32: each
 #       is a whole lambda expression on one line); the planar branches (:196-197, :217-218) read AVFrame fields inside the same
 #       statement and are not compiled
@@ -30,6 +31,8 @@ sed -n '627p' $BIMIX | grep -q 'dst = (left + right) \* 0.5;'
 sed -n '799p' $BIMIX | grep -q 'for (size_t i = 0; i < eariler_stream.front().samples.size(); i++)'
 sed -n '837p' $BIMIX | grep -q 'for (size_t i = 0; i < unaligned_samples; i++)'
 sed -n '850p' $BIMIX | grep -q '^[[:space:]]*}$'
+sed -n '379p' $AMIX | grep -q 'float unlocked_volume_sum = 0.0f;'
+sed -n '386p' $AMIX | grep -q 'volumes\[i\] /= unlocked_volume_sum;'
 sed -n '186p' $VELO | grep -q '\[\](int16_t sample) { return static_cast<float>(sample) / 32768.0f; }'
 sed -n '207p' $VELO | grep -q '\[\](int32_t sample) { return static_cast<float>(sample) / 2147483648.0f; }'
 cat <<'PRE'
@@ -125,4 +128,14 @@ cat <<'POST3'
     ;
     for (size_t k = 0; k < n; k++) out[k] = convert(in[k]);
 }
+#include <algorithm>
+extern "C" void ref_amix_normalise(float* volumes_io, const unsigned char* locks_in, int input_num)
+{
+    std::vector<float> volumes(volumes_io, volumes_io + input_num);      // include/processor/audio-amix.hpp:37-38
+    std::vector<bool> locks(locks_in, locks_in + input_num);
 POST3
+sed -n '379,387p' $AMIX
+cat <<'POST4'
+    for (int k = 0; k < input_num; k++) volumes_io[k] = volumes[k];
+}
+POST4

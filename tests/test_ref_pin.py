@@ -244,3 +244,22 @@ def test_k6_packed_integer_lambdas_of_the_reference(refmix, dtype, fn, fmt):
     f(x.ctypes.data, got.ctypes.data, x.size)
     rc, want = orc.to_f32_interleaved(fmt, [x], x.size // 2, 2)      # packed stereo: one plane of S * 2 samples
     assert rc == 0 and same_bits(got, want)
+
+
+def test_k3_weight_renormalisation_of_the_reference(refmix):
+    """audio-amix.cpp:379-387: the unlocked weights are scaled to sum 1 (floor 0.001); loops with their headers"""
+    refmix.ref_amix_normalise.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    refmix.ref_amix_normalise.restype = None
+    rng = np.random.default_rng(9)
+    for n in (1, 2, 5, 16):
+        for trial in range(20):
+            v = rng.uniform(0, 1, n).astype(np.float32)
+            locks = (rng.uniform(0, 1, n) < 0.3).astype(np.uint8)
+            if trial == 0:
+                v[:] = 0                                  # the 0.001 floor
+            if trial == 1:
+                locks[:] = 1                              # nothing unlocked
+            want = orc.amix_normalise(v, locks)
+            got = v.copy()
+            refmix.ref_amix_normalise(got.ctypes.data, locks.ctypes.data, n)
+            assert same_bits(got, want), (n, trial)
