@@ -264,6 +264,17 @@ def main():
                 roofline["valu"]["issue_plus_lds"] = {"valu_cycles_per_cu": v_cyc, "lds_cycles_per_cu": l_cyc, "kernel_cycles": avg_s * clock_ghz * 1e9,
                                                       "frac": round((v_cyc + l_cyc) / (avg_s * clock_ghz * 1e9), 3)}
     chain_gbs = 64.03 * (n_streams * S * a.steps / elapsed) / 1e9   # 24 + 16 + 24.03 B per sample-frame, rank 0's GPU
+    # the two memory-side kernels against what a PLAIN streaming kernel with their read : write mix reaches on this chip
+    # (tools/ubench/rw_mix.hip -> profiles/r04_rw_mix.md, 4096 workgroups; nt stores in brackets): real HBM bytes (PMC passes) / duration
+    PLAIN_GBPS = {"spectrum_stereo_kernel": ("1 read : 2 writes", 4670.0, 5080.0), "mix_resample_tile_kernel": ("2 reads : 3 writes", 4700.0, 4800.0)}
+    memory_side = {}
+    for name, (mix, plain, plain_nt) in PLAIN_GBPS.items():
+        td = tdata.get(name, {})
+        if name in kernels and td.get("hbm_bytes_per_launch") and td.get("sample_frames"):
+            avg_s = kernels[name][0] / max(kernels[name][1], 1) * 1e-3
+            gbs = td["hbm_bytes_per_launch"] * (sf / td["sample_frames"]) / avg_s / 1e9
+            memory_side[name] = {"hbm_GBps": round(gbs, 1), "read_write_mix": mix, "plain_streaming_kernel_GBps": plain,
+                                 "plain_streaming_kernel_nt_GBps": plain_nt, "frac_of_plain": round(gbs / plain, 3)}
 
     out = {
         "metric": "stereo f32 sample-frames/s through the 4-node graph input->mix(2)->pitch->FFT-spectrum @48 kHz",
@@ -280,6 +291,7 @@ def main():
         "chain": {"alg_bytes_per_sample_frame": 64.03, "alg_GBps_per_gpu": round(chain_gbs, 1),
                   "frac_hbm_peak": round(chain_gbs / HBM_PEAK_GBS, 4)},
         "kernels": kern_report,
+        "memory_side": memory_side,
     }
 
     # ---- the same pitch node with the SoundTouch-shaped WSOLA chain (K7 option A) instead of the phase vocoder:
