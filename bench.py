@@ -129,8 +129,7 @@ def main():
         if rank == 0:
             ctx.fill_uniform(t_b.data_ptr(), S * 2, 0, 1, 0, 1)
             ctx.sync()
-        shard.broadcast_shared(dist, t_b, 0)
-        torch.cuda.synchronize()
+        bcast_ms, bcast_bytes = shard.timed_broadcast_shared(dist, t_b, 0, sync=torch.cuda.synchronize)
         b_ptr = t_b.data_ptr()
     else:
         d_b = ctx.empty(S * 2)
@@ -194,7 +193,12 @@ def main():
                 break
         ts1 = time.perf_counter()
         sustained = {"seconds": round(ts1 - ts0, 2), "steps": n_sus, "ms_per_step": (ts1 - ts0) / n_sus * 1e3, "clock_GHz_after": round(ctx.clock_ghz(), 3)}
+    ranks = None
     if dist is not None:
+        # every rank's own figures, gathered before the maximum replaces them: the N > 1 line explains itself
+        ranks = shard.gather_rank_reports(dist, {"rank": rank, "first_stream": first_stream, "last_stream": last_stream, "streams": n_streams,
+                                                 "ms_per_step": elapsed / a.steps * 1e3, "clock_GHz": clock_ghz, "broadcast_ms": bcast_ms,
+                                                 "broadcast_bytes": bcast_bytes}, device=f"cuda:{local_rank}")
         elapsed = shard.max_over_ranks(dist, elapsed, device=f"cuda:{local_rank}")
         dist.barrier()
 
@@ -293,6 +297,13 @@ def main():
         "kernels": kern_report,
         "memory_side": memory_side,
     }
+    if ranks is not None:
+        # (src/infra/runner.cpp:35-50, 142-154: one product per link, every branch runs by itself — the ranks share only the broadcast)
+        out["ranks"] = {"ranks_seen": ranks["ranks_seen"], "backend": "nccl (RCCL)", "launched_world_size": world,
+                        "collective": "one broadcast of the shared second mix input from rank 0 at setup; the timed region has none",
+                        "per_rank": ranks["per_rank"],
+                        "slowest_rank": max(ranks["per_rank"], key=lambda d: d["ms_per_step"])["rank"],
+                        "streams_covered": sum(d["streams"] for d in ranks["per_rank"])}
 
     # ---- the same pitch node with the SoundTouch-shaped WSOLA chain (K7 option A) instead of the phase vocoder:
     # reported beside the headline, never part of `value`

@@ -227,6 +227,7 @@ int nae_ctx_create(int device, nae_ctx** out)
     ctx->dbg_st_unfused = getenv("NAE_ST_UNFUSED") != nullptr;
     ctx->dbg_rs_direct = getenv("NAE_RS_DIRECT") != nullptr;
     ctx->dbg_spec_generic = getenv("NAE_SPEC_GENERIC") != nullptr;
+    ctx->dbg_spec_narrow = getenv("NAE_SPEC_NARROW") != nullptr;
     ctx->pv_lean = getenv("NAE_PV_LEAN") != nullptr;
     if (const char* e = getenv("NAE_SPEC_CHUNK")) ctx->dbg_spec_chunk = atoi(e);
     std::vector<nae::cf> w512, t1024;

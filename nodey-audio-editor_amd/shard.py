@@ -64,3 +64,40 @@ def job_throughput(world: int, per_rank_streams: int, frames_per_stream: int, st
 def job_throughput_total(total_streams: int, frames_per_stream: int, steps: int, elapsed_s: float) -> float:
     """strong mode: the job's `total_streams` (however they were cut) over the slowest rank's time"""
     return total_streams * frames_per_stream * steps / elapsed_s
+
+
+RANK_REPORT_FIELDS = ("rank", "first_stream", "last_stream", "streams", "ms_per_step", "clock_GHz", "broadcast_ms", "broadcast_bytes")
+
+
+def timed_broadcast_shared(dist, tensor, src: int = 0, sync=None):
+    """broadcast_shared with this rank's wall time around it (ms) and the bytes moved; `sync` (e.g. torch.cuda.synchronize) is
+    called before both clock readings so that the time covers the transfer, not its enqueueing"""
+    import time
+    if sync is not None:
+        sync()
+    t0 = time.perf_counter()
+    dist.broadcast(tensor, src=src)
+    if sync is not None:
+        sync()
+    return (time.perf_counter() - t0) * 1e3, tensor.numel() * tensor.element_size()
+
+
+def gather_rank_reports(dist, report: dict, device=None) -> dict:
+    """What every rank of the job saw, gathered on every rank (one all_gather of eight doubles per rank): the N > 1 bench line
+    carries it so that the line says by itself how many ranks the collective library connected (`ranks_seen` = the process
+    group's world size AFTER the broadcast went through it), which streams each rank owned, and each rank's own step time and
+    clock.  `report` holds RANK_REPORT_FIELDS; the result is {"ranks_seen": n, "per_rank": [dict per rank, in rank order]}."""
+    import torch
+    mine = torch.tensor([float(report[k]) for k in RANK_REPORT_FIELDS], dtype=torch.float64, device=device)
+    world = dist.get_world_size()
+    rows = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(rows, mine)
+    per_rank = []
+    for row in rows:
+        vals = row.cpu().tolist()
+        d = dict(zip(RANK_REPORT_FIELDS, vals))
+        for k in ("rank", "first_stream", "last_stream", "streams", "broadcast_bytes"):
+            d[k] = int(d[k])
+        per_rank.append(d)
+    per_rank.sort(key=lambda d: d["rank"])
+    return {"ranks_seen": world, "per_rank": per_rank}

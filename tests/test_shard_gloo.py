@@ -37,9 +37,14 @@ def _worker(rank, world, port, total, n, q):
     if rank == 0:
         shared = torch.from_numpy(orc.fill_uniform(n, shard.stream_seed(0, 1)))
     shard.broadcast_shared(dist, shared, 0)
+    bms, bbytes = shard.timed_broadcast_shared(dist, shared, 0)          # the timed form bench.py uses (a second, idempotent broadcast)
+    # the per-rank report of bench.py's N > 1 line, gathered the way bench.py gathers it
+    ranks = shard.gather_rank_reports(dist, {"rank": rank, "first_stream": first, "last_stream": last, "streams": last - first,
+                                             "ms_per_step": 10.0 * (rank + 1), "clock_GHz": 2.0 + 0.1 * rank, "broadcast_ms": bms,
+                                             "broadcast_bytes": bbytes})
     elapsed = shard.max_over_ranks(dist, 0.010 * (rank + 1))
     dist.barrier()
-    q.put((rank, first, last, [float(m[0]) for m in mine], shared.numpy().copy(), elapsed))
+    q.put((rank, first, last, [float(m[0]) for m in mine], shared.numpy().copy(), elapsed, ranks))
     dist.destroy_process_group()
 
 
@@ -59,8 +64,19 @@ def test_two_rank_sharding_and_broadcast():
         p.join(timeout=60)
         assert p.exitcode == 0
     ref_shared = orc.fill_uniform(n, (0x9E3779B97F4A7C15 * 1 + 1) & 0xFFFFFFFFFFFFFFFF)
+    import naeload
+    naeload.load()
+    from nodey_audio_editor_amd import shard as _shard
+    shard_fields = _shard.RANK_REPORT_FIELDS
     covered = []
-    for rank, first, last, firsts, shared, elapsed in res:
+    for rank, first, last, firsts, shared, elapsed, ranks in res:
+        # every rank holds the same report: both ranks seen, their slices, their own step times and clocks, the broadcast's size
+        assert ranks["ranks_seen"] == world and [d["rank"] for d in ranks["per_rank"]] == list(range(world))
+        assert [(d["first_stream"], d["last_stream"], d["streams"]) for d in ranks["per_rank"]] == [(0, 2, 2), (2, 5, 3)]
+        assert [d["ms_per_step"] for d in ranks["per_rank"]] == [10.0, 20.0]
+        assert [round(d["clock_GHz"], 6) for d in ranks["per_rank"]] == [2.0, 2.1]
+        assert all(d["broadcast_bytes"] == 4 * n and d["broadcast_ms"] >= 0.0 for d in ranks["per_rank"])
+        assert set(ranks["per_rank"][0]) == set(shard_fields)
         assert (first, last) == (rank * total // world, (rank + 1) * total // world)
         covered += list(range(first, last))
         assert np.array_equal(shared, ref_shared)               # broadcast delivered rank 0's buffer
