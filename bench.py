@@ -26,10 +26,12 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
 SEMITONES = 3.0
 BINS = 513
-# issue interval of an add/sub/mul/fma mix, cycles per wave-instruction per SIMD, by waves resident per SIMD (s_memtime,
-# tools/ubench/valu_issue.hip -> profiles/r02_valu_issue.md, row "add/sub/mul/fma mix of a radix-8 butterfly").  The 5-wave entry is
-# INTERPOLATED between the measured 4- and 6-wave rows (the micro-benchmark has no 5-wave row).
-VALU_MIX_CYCLES_PER_INSTR = {1: 5.44, 2: 2.72, 3: 1.82, 4: 1.94, 5: 1.8, 6: 1.65, 8: 1.26}
+# vector issue: cycles per wave64 f32 instruction per SIMD (add/sub/mul/fma mix), measured by WALL CLOCK and by SQ counters
+# (tools/ubench/valu_wallclock.hip -> profiles/r05_valu_wallclock.md): 4.6 for a lone wave, 2.15-2.2 for two or more waves per SIMD
+# (= the chip guide's 2 cycles per wave64 instruction on a SIMD-32; v_fma_f32 130 TFLOP/s at the 2.13 GHz held under that load).
+# Rounds 2-4 used an s_memtime table (1.26 at 8 waves, 1.94 at 4) that implied 195 TFLOP/s: superseded.
+def valu_cycles_per_instr(waves_per_simd):
+    return 4.6 if waves_per_simd <= 1 else 2.15
 
 
 def parse():
@@ -247,26 +249,25 @@ def main():
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "traffic_source": tdata.get("_source") if traffic is not None else None,
                     "avg_launch_ms": round(avg_s * 1e3, 4), "alg_bytes_per_launch": alg_bytes.get(dom, 0.0),
-                    "note": "K7 is bound by vector-instruction issue PLUS LDS time (two 512-point FFTs, atan2, sin/cos per bin), not by HBM: on "
-                            "gfx950 the two add up instead of overlapping (valu.issue_plus_lds; DESIGN.md §4 and profiles/)"}
+                    "note": "K7 is bound by the vector ALU (two 512-point FFTs, atan2, sin/cos per bin: ~78 % busy at 2.15 cycles per wave64 "
+                            "instruction), with the LDS array busy beside it, not by HBM (valu block; DESIGN.md §4 and profiles/r05_valu_wallclock.md)"}
         if scale and "valu_instr_per_launch" in td:
-            # vector-instruction issue: dynamic wave-instructions of the launch (SQ_INSTS_VALU) against the issue interval measured
-            # with s_memtime for an add/sub/mul/fma mix at this kernel's waves per SIMD (profiles/r02_valu_issue.md), at the clock
-            # measured in this run.  1024 SIMDs = 256 CUs x 4.
+            # vector ALU: dynamic wave-instructions of the launch (SQ_INSTS_VALU) x 2.15 cycles per wave-instruction per SIMD (wall-clock
+            # measured, profiles/r05_valu_wallclock.md) against the kernel's cycles at the clock measured in this run.  1024 SIMDs = 256 CUs x 4.
+            # The LDS array's cycles (SQ_LDS_IDX_ACTIVE per CU) run BESIDE the vector ALU: the two overlap partially, they do not add.
             instr = td["valu_instr_per_launch"] * scale
-            ach_cpi = avg_s * clock_ghz * 1e9 * 1024 / instr
-            peak_cpi = VALU_MIX_CYCLES_PER_INSTR[td.get("waves_per_simd", 6)]
+            k_cyc = avg_s * clock_ghz * 1e9
+            ach_cpi = k_cyc * 1024 / instr
+            peak_cpi = valu_cycles_per_instr(td.get("waves_per_simd", 6))
+            l_cyc = td["lds_idx_active_per_cu"] * scale if td.get("lds_idx_active_per_cu") else None
             roofline["valu"] = {"wave_instr_per_launch": instr, "clock_GHz": round(clock_ghz, 3), "waves_per_simd": td.get("waves_per_simd", 6),
                                 "achieved": round(ach_cpi, 3), "peak": peak_cpi, "unit": "cycles per wave-instruction per SIMD (lower is better)",
                                 "frac": round(peak_cpi / ach_cpi, 3),
-                                "lds": {"idx_active_cycles_per_cu": td.get("lds_idx_active_per_cu", None) and td["lds_idx_active_per_cu"] * scale,
-                                        "kernel_cycles": avg_s * clock_ghz * 1e9}}
-            if td.get("lds_idx_active_per_cu"):
-                # what the kernel's time is made of: vector issue at the measured interval + LDS-array cycles, per CU
-                v_cyc = instr / 1024.0 * peak_cpi
-                l_cyc = td["lds_idx_active_per_cu"] * scale
-                roofline["valu"]["issue_plus_lds"] = {"valu_cycles_per_cu": v_cyc, "lds_cycles_per_cu": l_cyc, "kernel_cycles": avg_s * clock_ghz * 1e9,
-                                                      "frac": round((v_cyc + l_cyc) / (avg_s * clock_ghz * 1e9), 3)}
+                                "peak_source": "profiles/r05_valu_wallclock.md (hipEvent wall clock + SQ_INSTS_VALU / GRBM_GUI_ACTIVE)",
+                                "valu_busy_cycles_per_simd": instr / 1024.0 * peak_cpi, "kernel_cycles": k_cyc,
+                                "lds": {"idx_active_cycles_per_cu": l_cyc, "frac_of_kernel": round(l_cyc / k_cyc, 3) if l_cyc else None,
+                                        "note": "runs beside the vector ALU (valu + lds > kernel cycles: partial overlap, not a sum)"},
+                                "floor_ms_at_this_clock": round(instr / 1024.0 * peak_cpi / (clock_ghz * 1e9) * 1e3, 3)}
     chain_gbs = 64.03 * (n_streams * S * a.steps / elapsed) / 1e9   # 24 + 16 + 24.03 B per sample-frame, rank 0's GPU
     # the two memory-side kernels against what a PLAIN streaming kernel with their read : write mix reaches on this chip
     # (tools/ubench/rw_mix.hip -> profiles/r04_rw_mix.md, 4096 workgroups; nt stores in brackets): real HBM bytes (PMC passes) / duration
@@ -341,12 +342,13 @@ def main():
             scale = sf / td["sample_frames"]
             instr = td["valu_instr_per_launch"] * scale
             cyc = avg_ms * 1e-3 * clock_ghz * 1e9
-            peak_cpi = VALU_MIX_CYCLES_PER_INSTR[td.get("waves_per_simd", 4)]
+            peak_cpi = valu_cycles_per_instr(td.get("waves_per_simd", 4))
             v_cyc, l_cyc = instr / 1024.0 * peak_cpi, td.get("lds_idx_active_per_cu", 0.0) * scale
             valu[kname] = {"wave_instr_per_launch": instr, "waves_per_simd": td.get("waves_per_simd", 4),
                            "achieved": round(cyc * 1024 / instr, 3), "peak": peak_cpi, "unit": "cycles per wave-instruction per SIMD (lower is better)",
                            "frac": round(peak_cpi * instr / 1024 / cyc, 3),
-                           "issue_plus_lds": {"valu_cycles_per_cu": v_cyc, "lds_cycles_per_cu": l_cyc, "kernel_cycles": cyc, "frac": round((v_cyc + l_cyc) / cyc, 3)}}
+                           "valu_busy_cycles_per_simd": v_cyc, "lds_cycles_per_cu": l_cyc, "kernel_cycles": cyc,
+                           "floor_ms_at_this_clock": round(v_cyc / (clock_ghz * 1e9) * 1e3, 3)}
         if valu:
             out["pitch_node_soundtouch_algorithm"]["valu"] = valu
             out["pitch_node_soundtouch_algorithm"]["valu_source"] = wdata.get("_source")

@@ -26,7 +26,12 @@
 extern "C" {
 #endif
 
-#define NAE_ABI_VERSION 1
+/* ABI version.  2 (round 5): additions since 1 — nae_event_query, nae_ctx_wait_event, nae_debug_graph4_stages, page-locked memory,
+ * nae_wsola_*, nae_swr_* — and one CHANGED behaviour: nae_ctx_create of a second device used to return NAE_ERR_UNSUPPORTED behind a
+ * process-wide latch; now a context may sit on any device, and an index outside [0, nae_device_count()) is NAE_ERR_INVALID.
+ * A caller built against 1 keeps working (nothing was removed or re-typed); a caller that needs the additions checks
+ * nae_abi_version() >= 2. */
+#define NAE_ABI_VERSION 2
 
 typedef enum nae_status {
     NAE_OK = 0,
@@ -53,14 +58,21 @@ int nae_abi_version(void);
 int nae_device_count(void);
 /* Devices.  A process may hold contexts on SEVERAL devices (the reference runs every node of a graph in one process on one
  * thread, src/infra/runner.cpp:65-83,142-154, so the drop-in reaches all GPUs of the node from there): a context remembers
- * its device, and every entry point that allocates, launches or records selects that device for the calling thread when the
- * thread's current HIP device differs — and leaves it selected.  `device` outside [0, nae_device_count()) returns
+ * its device, and every entry point that takes a context — allocation, launches, copies, memset, event record / wait, nae_sync,
+ * nae_poll, nae_free — selects that device for the calling thread when the thread's current HIP device differs, and leaves it
+ * selected.  `device` outside [0, nae_device_count()) returns
  * NAE_ERR_INVALID.  Several contexts on one device are fine — each has its own stream, so their work overlaps.
  * (More than one device per process is exercised on one-GPU boxes only, through two contexts on device 0 and the
  * rejection of device 1: N > 1 devices from one process are UNMEASURED on hardware.)
- * Threads.  The library keeps no process-global mutable state.  ONE thread at a time drives a given context and the
+ * Threads.  The library keeps no process-global mutable HOST state.  ONE thread at a time drives a given context and the
  * handles / events created from it; different contexts may be created, driven and destroyed from different threads
- * concurrently.  nae_event_query / nae_poll may be called from the thread that drives the context. */
+ * concurrently.  nae_event_query / nae_poll may be called from the thread that drives the context.
+ * One piece of DEVICE-global state exists: `g_cu_arrivals` (csrc/kernels_pvpipe.hip), per-CU arrival counters from which the
+ * vocoder pipeline's two workgroups of a CU derive which of them starts with the higher issue priority.  It is shared by all
+ * contexts of a device and never reset; two contexts running the pipeline concurrently can hand both workgroups of a CU the
+ * same parity — a scheduling hint only: results do not depend on it (tests/test_gpu_multi_ctx.py runs two contexts interleaved
+ * bit for bit).  The host mirror's own shared state (context pool, device round-robin) is guarded by a mutex
+ * (host/processor/gpu-context.hpp); it keeps every node on ONE device unless $NAE_DEVICES asks for more. */
 int nae_ctx_create(int device, nae_ctx** out);
 int nae_ctx_destroy(nae_ctx* ctx);
 int nae_ctx_set_stream(nae_ctx* ctx, void* hip_stream); /* borrow a hipStream_t (e.g. torch's current stream) */

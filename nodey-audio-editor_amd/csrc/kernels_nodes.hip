@@ -521,6 +521,7 @@ int nae_debug_diff_u32(nae_ctx* ctx, const void* a, const void* b, size_t n_word
     if (n_words == 0) return NAE_OK;
     size_t blocks = (n_words + 255) / 256;
     if (blocks > 8192) blocks = 8192;
+    (void)nae_use_device(ctx);
     hipLaunchKernelGGL(diff_u32_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, static_cast<const uint32_t*>(a),
                        static_cast<const uint32_t*>(b), n_words, reinterpret_cast<unsigned long long*>(d_count));
     return nae_check(ctx, hipGetLastError(), "diff_u32_kernel");

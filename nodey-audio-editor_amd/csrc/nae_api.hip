@@ -277,12 +277,14 @@ void* nae_ctx_stream(nae_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; 
 int nae_sync(nae_ctx* ctx)
 {
     if (!ctx) return NAE_ERR_INVALID;
+    (void)nae_use_device(ctx);
     return nae_check(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
 }
 
 int nae_poll(nae_ctx* ctx)
 {
     if (!ctx) return NAE_ERR_INVALID;
+    (void)nae_use_device(ctx);
     hipError_t e = hipStreamQuery(ctx->stream);
     if (e == hipSuccess) return 1;
     if (e == hipErrorNotReady) return 0;
@@ -305,6 +307,7 @@ int nae_malloc(nae_ctx* ctx, size_t bytes, void** dptr)
 int nae_free(nae_ctx* ctx, void* dptr)
 {
     if (!dptr) return NAE_OK;
+    if (ctx) (void)nae_use_device(ctx);
     return nae_check(ctx, hipFree(dptr), "hipFree");
 }
 int nae_malloc_host(nae_ctx* ctx, size_t bytes, void** hptr)
@@ -320,26 +323,31 @@ int nae_malloc_host(nae_ctx* ctx, size_t bytes, void** hptr)
 int nae_free_host(nae_ctx* ctx, void* hptr)
 {
     if (!hptr) return NAE_OK;
+    if (ctx) (void)nae_use_device(ctx);
     return nae_check(ctx, hipHostFree(hptr), "hipHostFree");
 }
 int nae_memcpy_h2d(nae_ctx* ctx, void* dst, const void* src, size_t bytes)
 {
     if (!ctx || (bytes && (!dst || !src))) return NAE_ERR_INVALID;
+    (void)nae_use_device(ctx);
     return nae_check(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync(h2d)");
 }
 int nae_memcpy_d2h(nae_ctx* ctx, void* dst, const void* src, size_t bytes)
 {
     if (!ctx || (bytes && (!dst || !src))) return NAE_ERR_INVALID;
+    (void)nae_use_device(ctx);
     return nae_check(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync(d2h)");
 }
 int nae_memcpy_d2d(nae_ctx* ctx, void* dst, const void* src, size_t bytes)
 {
     if (!ctx || (bytes && (!dst || !src))) return NAE_ERR_INVALID;
+    (void)nae_use_device(ctx);
     return nae_check(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream), "hipMemcpyAsync(d2d)");
 }
 int nae_memset(nae_ctx* ctx, void* dst, int value, size_t bytes)
 {
     if (!ctx || (bytes && !dst)) return NAE_ERR_INVALID;
+    (void)nae_use_device(ctx);
     return nae_check(ctx, hipMemsetAsync(dst, value, bytes, ctx->stream), "hipMemsetAsync");
 }
 
@@ -356,6 +364,7 @@ int nae_event_create(nae_ctx* ctx, nae_event** ev)
 int nae_event_record(nae_ctx* ctx, nae_event* ev)
 {
     if (!ctx || !ev) return NAE_ERR_INVALID;
+    (void)nae_use_device(ctx);
     return nae_check(ctx, hipEventRecord(ev->ev, ctx->stream), "hipEventRecord");
 }
 int nae_event_query(nae_event* ev)
@@ -369,6 +378,7 @@ int nae_event_query(nae_event* ev)
 int nae_ctx_wait_event(nae_ctx* ctx, nae_event* ev)
 {
     if (!ctx || !ev) return NAE_ERR_INVALID;
+    (void)nae_use_device(ctx);
     return nae_check(ctx, hipStreamWaitEvent(ctx->stream, ev->ev, 0), "hipStreamWaitEvent");
 }
 int nae_event_elapsed_ms(nae_event* start, nae_event* stop, float* ms)

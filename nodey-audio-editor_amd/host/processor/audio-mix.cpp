@@ -165,7 +165,7 @@ namespace processor
 		std::any&
 	)
 	{
-		gpu::Node node;  // this node's context (own stream, device by round-robin): first local, destroyed last
+		gpu::Node node;  // this node's context (own stream; device: gpu::pick_device): first local, destroyed last
 		const int input_num = this->input_num;
 		if (input_num < 1 || input_num > 16) throw Runtime_error("Invalid input count", "The mixer supports 1 to 16 inputs.", infra::fmt("input_num = %d", input_num));
 		if ((int)volumes.size() != input_num)  // the reference indexes an empty vector here (audio-amix.cpp:302) unless draw_content/deserialize ran
@@ -405,7 +405,7 @@ namespace processor
 		std::any&
 	)
 	{
-		gpu::Node node;  // this node's context (own stream, device by round-robin): first local, destroyed last
+		gpu::Node node;  // this node's context (own stream; device: gpu::pick_device): first local, destroyed last
 		std::vector<std::shared_ptr<const Audio_frame>> buf_l, buf_r;
 		bool left_eof = false, right_eof = false;
 		double time_seconds = 0;
@@ -535,7 +535,7 @@ namespace processor
 		std::any&
 	)
 	{
-		gpu::Node node;  // this node's context (own stream, device by round-robin): first local, destroyed last
+		gpu::Node node;  // this node's context (own stream; device: gpu::pick_device): first local, destroyed last
 		auto in_l = infra::get_input_item<Audio_stream>(input, "input_l");
 		auto in_r = infra::get_input_item<Audio_stream>(input, "input_r");
 		if (!in_l.has_value() || !in_r.has_value())

@@ -1,5 +1,6 @@
 #include "audio-velocity.hpp"
 #include "gpu-context.hpp"
+#include "velocity-cadence.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -184,7 +185,7 @@ namespace processor
 			Stretch_algorithm algorithm, Batch_stats& batch_stats
 		)
 		{
-			gpu::Node node;  // this node's context (own stream, device by round-robin): first local, destroyed last
+			gpu::Node node;  // this node's context (own stream; device: gpu::pick_device): first local, destroyed last
 			batch_stats = {};
 			const auto input_item = infra::get_input_item<Audio_stream>(input, "input");
 			const auto output_stream = infra::get_output_item<Audio_stream>(output, "output");
@@ -200,24 +201,18 @@ namespace processor
 			gpu::Pinned_buffer h_raw, h_out;
 			bool input_stream_eof = false, pending_put = false;
 			std::shared_ptr<const Audio_frame> held;  // popped, but with another channel count than the batch in front of it
-			const double time_ratio = 1.0f / velocity;
 			int channel_count = 0, sample_rate = 0;
 			double time_seconds = 0.0;
 
 			// receiveSamples + construct_audio_frame_float + push (:294-316), for every chunk that is ready at once: the chunk sizes are
 			// those the reference's loop would take one per turn (min(numSamples, max) while more than `floor` samples are queued); all
 			// of them come down as ONE asynchronous copy into page-locked staging behind ONE wait, then they are cut into frames
-			auto acquire_chunks = [&](size_t floor, uint32_t max_samples)
+			const cadence::Bounds chunk_bounds = cadence::bounds(velocity);  // :416-417
+			auto acquire_chunks = [&](size_t floor)
 			{
-				std::vector<size_t> chunks;
-				size_t avail = soundtouch.available(), total = 0;
-				while (avail > floor)
-				{
-					const size_t take = std::min<size_t>(avail, std::max<uint32_t>(max_samples, 1));
-					chunks.push_back(take);
-					total += take;
-					avail -= take;
-				}
+				const std::vector<size_t> chunks = cadence::drain(soundtouch.available(), floor, chunk_bounds);
+				size_t total = 0;
+				for (const size_t take : chunks) total += take;
 				if (chunks.empty()) return;
 				nae_ctx* ctx = gpu::context();
 				float* dev = static_cast<float*>(d_out.reserve(total * channel_count * sizeof(float)));
@@ -307,13 +302,12 @@ namespace processor
 				if (soundtouch.open())
 				{
 					// (:414 "numSamples() == 0 && eof -> break" is subsumed by the flush branch)
-					const uint32_t min_samples = time_ratio * 1152;
-					const uint32_t max_samples = time_ratio * 1152 * 3;
+					const uint32_t min_samples = chunk_bounds.min_samples;
 					if (soundtouch.available() > min_samples)
 					{
 						// the reference receives one chunk per loop turn because it puts one frame per turn (:403,416-424); a batched put
 						// makes several chunks available, and all of them are taken now (chunk sizes stay inside [min, max])
-						acquire_chunks(min_samples, max_samples);
+						acquire_chunks(min_samples);
 						pending_put = false;
 						batch_stats.waits++;
 					}
@@ -322,7 +316,7 @@ namespace processor
 						soundtouch.flush();
 						// the reference emits ONE frame with everything that is left (:427-433); here flush() may release
 						// the whole stream, so it is cut into the same [min, max] chunks the steady state uses
-						acquire_chunks(0, max_samples);
+						acquire_chunks(0);
 						break;
 					}
 					if (pending_put)
@@ -420,12 +414,14 @@ namespace processor
 		const std::atomic<bool>& stop_token, std::any&
 	)
 	{
+		gpu::Node node;  // this node's context (own stream): first local, destroyed last — before the handle guard and the buffers
 		const auto input_item = infra::get_input_item<Audio_stream>(input, "input");
 		const auto output_stream = infra::get_output_item<Audio_stream>(output, "output");
 		if (!input_item.has_value())
 			throw Runtime_error("FFT Spectrum has no input", "FFT Spectrum requires an audio stream input to function properly.", "Input item 'input' not found");
 		Audio_stream& input_stream = input_item.value().get();
 		nae_ctx* ctx = gpu::context();
+		last_context = ctx;
 		nae_spectrum* spectrum = nullptr;
 		struct Guard { nae_spectrum*& h; ~Guard() { if (h) nae_spectrum_destroy(h); } } guard{spectrum};
 		gpu::Device_buffer d_raw, d_f32, d_out;

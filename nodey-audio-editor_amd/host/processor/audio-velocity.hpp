@@ -70,6 +70,8 @@ namespace processor
 	{
 	  public:
 
+		const void* last_context = nullptr;  // the nae_ctx its last process_payload ran on (every running node owns one: gpu-context.hpp); tests only
+
 		static infra::Processor::Info get_processor_info();
 		Processor::Info get_processor_info_non_static() const override { return get_processor_info(); }
 		std::vector<infra::Processor::Pin_attribute> get_pin_attributes() const override;

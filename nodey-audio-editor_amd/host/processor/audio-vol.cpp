@@ -29,7 +29,7 @@ namespace processor
 		std::any&
 	)
 	{
-		gpu::Node node;  // this node's context (own stream, device by round-robin): first local, destroyed last
+		gpu::Node node;  // this node's context (own stream; device: gpu::pick_device): first local, destroyed last
 		const auto input_item_optional = infra::get_input_item<Audio_stream>(input, "input");
 		const auto output_item = infra::get_output_item<Audio_stream>(output, "output");
 		if (!input_item_optional.has_value())

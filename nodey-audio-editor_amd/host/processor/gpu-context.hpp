@@ -5,10 +5,15 @@
 //   * a node waits for ITS OWN batch — gpu::wait polls the node's stream, not a stream shared with every other node of the graph
 //     (round 3: one process-wide context; a node whose batch had finished kept yielding while any other node's was queued);
 //   * batches of different nodes overlap on the device;
-//   * nodes are spread over the GPUs of the machine: node k of a run goes to device k mod nae_device_count() (the reference runs the
-//     whole graph in ONE process on ONE thread, src/infra/runner.cpp:142-154; every hop between nodes passes host frames anyway —
-//     Audio_stream carries AVFrames — so any node can sit on any device).  $NAE_DEVICE pins all nodes to one device, $NAE_DEVICES
-//     limits the spread to the first n.
+//   * nodes MAY be spread over the GPUs of the machine: with $NAE_DEVICES=n node k of a run goes to device k mod min(n, nae_device_count())
+//     (the reference runs the whole graph in ONE process on ONE thread, src/infra/runner.cpp:142-154; every hop between nodes passes
+//     host frames anyway — Audio_stream carries AVFrames — so any node can sit on any device).  WITHOUT $NAE_DEVICES every node runs on
+//     ONE device ($NAE_DEVICE, default 0): more than one device from one process has never run on hardware here (one-GPU leases; the
+//     two-device test skips), so spreading is opt-in until it has.
+// Threads: one Runner thread drives all nodes of a run (cooperative fibers), but the editor builds the next Runner before it destroys the
+// previous one (src/frontend/app.cpp:2028; each Runner starts its fibers on a fresh detached std::thread, src/infra/runner.cpp:153), so a
+// finishing run's ~Node can meet a starting run's Node(): the pool, the counters and the device round-robin are guarded by ONE mutex.
+// A context itself is still driven by one thread at a time (include/nae_gpu.h, Threads).
 // The node's context is found through one pointer of fiber-local storage (boost::fibers::fiber_specific_ptr in the reference's
 // scheduler), so helpers deep inside a processor need no extra argument.
 #pragma once
@@ -20,6 +25,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <map>
+#include <mutex>
 #include <vector>
 
 namespace processor::gpu
@@ -43,17 +49,27 @@ namespace processor::gpu
 		static Flight_stats s;
 		return s;
 	}
+	// guards context_pool(), pick_device()'s counter and the creation / return of contexts (see "Threads" above); the per-wait counters of
+	// Flight_stats are statistics of ONE runner thread (the benchmark's) and stay unguarded
+	inline std::mutex& shared_state_mutex()
+	{
+		static std::mutex m;
+		return m;
+	}
 
 	inline Setup_timer::~Setup_timer() { flight_stats().setup_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
 
 	inline int pick_device()
 	{
-		static unsigned next = 0;
-		if (const char* dev = std::getenv("NAE_DEVICE")) return std::atoi(dev);
+		static unsigned next = 0;  // (under shared_state_mutex)
+		const char* dev = std::getenv("NAE_DEVICE");
+		const char* lim = std::getenv("NAE_DEVICES");
+		// one device unless the integrator asks for more: N > 1 devices per process are unmeasured on hardware (include/nae_gpu.h, Devices)
+		if (lim == nullptr || std::atoi(lim) <= 1) return dev ? std::atoi(dev) : 0;
 		int n = nae_device_count();
-		if (const char* lim = std::getenv("NAE_DEVICES"))
-			if (std::atoi(lim) > 0 && std::atoi(lim) < n) n = std::atoi(lim);
+		if (std::atoi(lim) < n) n = std::atoi(lim);
 		if (n <= 0) return 0;  // nae_ctx_create reports the missing device
+		std::lock_guard<std::mutex> lock(shared_state_mutex());
 		const int d = (int)(next++ % (unsigned)n);
 		if (d + 1 > flight_stats().devices_used) flight_stats().devices_used = d + 1;
 		return d;
@@ -69,15 +85,19 @@ namespace processor::gpu
 
 	inline nae_ctx* create_context(int device)
 	{
-		auto& free_list = context_pool()[device];
-		if (!free_list.empty())
 		{
-			nae_ctx* ctx = free_list.back();
-			free_list.pop_back();
-			return ctx;
+			std::lock_guard<std::mutex> lock(shared_state_mutex());
+			auto& free_list = context_pool()[device];
+			if (!free_list.empty())
+			{
+				nae_ctx* ctx = free_list.back();
+				free_list.pop_back();
+				return ctx;
+			}
+			flight_stats().contexts_created++;
+			if (flight_stats().devices_used < 1) flight_stats().devices_used = 1;
 		}
 		Setup_timer timer;
-		flight_stats().contexts_created++;
 		nae_ctx* ctx = nullptr;
 		const int rc = nae_ctx_create(device, &ctx);
 		if (rc != NAE_OK)
@@ -87,6 +107,20 @@ namespace processor::gpu
 				infra::fmt("nae_ctx_create(%d) returned %d", device, rc)
 			);
 		return ctx;
+	}
+
+	// a finished node's context goes back to the pool — unless its last synchronisation failed: a context in error state is destroyed,
+	// so the next run never inherits it
+	inline void return_context(int device, nae_ctx* ctx)
+	{
+		if (ctx == nullptr) return;
+		if (nae_sync(ctx) != NAE_OK)
+		{
+			nae_ctx_destroy(ctx);
+			return;
+		}
+		std::lock_guard<std::mutex> lock(shared_state_mutex());
+		context_pool()[device].push_back(ctx);  // kept for the next run's nodes (destroyed with the process)
 	}
 
 	// the context of one running node; declare it FIRST in process_payload (device buffers and handles die before it)
@@ -104,6 +138,7 @@ namespace processor::gpu
 		{
 			ctx_ = create_context(device);
 			nae_fiber::this_fiber::local() = this;
+			std::lock_guard<std::mutex> lock(shared_state_mutex());
 			flight_stats().nodes++;
 		}
 		Node(const Node&) = delete;
@@ -111,8 +146,7 @@ namespace processor::gpu
 		~Node()
 		{
 			nae_fiber::this_fiber::local() = outer;
-			nae_sync(ctx_);
-			context_pool()[device].push_back(ctx_);  // kept for the next run's nodes (destroyed with the process)
+			return_context(device, ctx_);
 		}
 		nae_ctx* ctx() const { return ctx_; }
 	};
@@ -124,12 +158,12 @@ namespace processor::gpu
 	inline nae_ctx* context()
 	{
 		if (Node* node = current_node()) return node->ctx();
+		static std::once_flag once;
 		static nae_ctx* fallback = nullptr;
-		if (fallback == nullptr)
-		{
+		std::call_once(once, [] {
 			const char* dev = std::getenv("NAE_DEVICE");
 			fallback = create_context(dev ? std::atoi(dev) : 0);
-		}
+		});
 		return fallback;
 	}
 

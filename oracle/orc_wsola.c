@@ -22,6 +22,11 @@
  * tests/golden/wsola_golden.npz, authored by a second, independently written restatement in numpy float32 block form
  * (tests/golden/st_numpy.py), (ii) the GPU path against this file, bit for bit, and (iii) signal-level properties
  * (length, pitch, tempo, chunk invariance).
+ * Two points of this restatement are ASSUMPTIONS about the library, not pins: (a) the mono anti-alias FIR accumulates its float
+ * products in ONE float accumulator in tap order (SoundTouch >= 2.1 typedefs LONG_SAMPLETYPE as float in float builds; the generic
+ * evaluateFilterMono is a plain in-order loop) — but SoundTouch is usually built with fast-math and auto-vectorised, so the library's
+ * actual mono summation order depends on its compiler; (b) the golden file above was regenerated from the numpy restatement when
+ * (a) changed (round 4), so that gate compares two restatements by the same author with each other, not with SoundTouch.
  */
 #include "nae_oracle.h"
 

@@ -10,6 +10,7 @@
 #include "../../oracle/nae_oracle.h"
 
 #include "processor/bimix-align.hpp"
+#include "processor/velocity-cadence.hpp"
 #include <cmath>
 #include <cstring>
 #include <iostream>
@@ -31,6 +32,7 @@ class Test_source : public infra::Processor
 	std::vector<float> samples;  // interleaved
 	int ch = 2, frame_size = 1152, format = AV_SAMPLE_FMT_FLT, sample_rate = 48000;
 	double start_seconds = 0.0;
+	bool one_at_a_time = false;  // push the next frame only once every consumer has taken the previous one (frames arrive singly)
 
 	static Info get_processor_info() { return {"test_source", "Test Source", false, [] { return std::unique_ptr<Processor>(new Test_source); }, ""}; }
 	Info get_processor_info_non_static() const override { return get_processor_info(); }
@@ -67,6 +69,9 @@ class Test_source : public infra::Processor
 				for (int i = 0; i < n * ch; i++) reinterpret_cast<int16_t*>(f->data[0])[i] = (int16_t)std::lrintf(src[i] * 32767.0f);
 			for (auto& o : outs)
 				while (!stop_token && o->try_push(frame) != channel_op_status::success) nae_fiber::this_fiber::yield();
+			if (one_at_a_time)
+				for (auto& o : outs)
+					while (!stop_token && o->buffered_count() > 0) nae_fiber::this_fiber::yield();
 		}
 		for (auto& o : outs) o->set_eof();
 	}
@@ -140,6 +145,78 @@ static double rel_rms(const std::vector<float>& a, const std::vector<float>& b)
 	double e = 0, r = 0;
 	for (size_t i = 0; i < a.size(); i++) { e += (double(a[i]) - b[i]) * (double(a[i]) - b[i]); r += double(b[i]) * b[i]; }
 	return std::sqrt(e / std::max(r, 1e-300));
+}
+
+// ---- the velocity / pitch node's output cadence (/root/reference/src/processor/audio-velocity.cpp:399-436), restated as the
+// reference runs it: per turn at most ONE put of one source frame and at most ONE receive.  `frames_per_turn` > 1 restates the
+// mirror's batched turn instead (that many frames put as one block, then the receive rule until it no longer fires).
+struct Cadence { std::vector<size_t> sizes; std::vector<int64_t> pts; size_t total = 0; };
+
+template <typename Put, typename Avail, typename Receive, typename Flush>
+static Cadence run_cadence(size_t S, int frame_size, float velocity, bool mirror, size_t frames_per_turn, Put put, Avail avail, Receive receive, Flush flush)
+{
+	const processor::cadence::Bounds b = processor::cadence::bounds(velocity);
+	Cadence c;
+	double time_seconds = 0.0;
+	auto emit = [&](size_t n) {
+		const size_t got = receive(n);
+		c.sizes.push_back(got);
+		c.pts.push_back((int64_t)(float)(time_seconds * 1000000));   // construct_audio_frame_float's float-typed clock (:238,249)
+		time_seconds += double(got) / 48000;
+		c.total += got;
+	};
+	size_t pos = 0;
+	bool eof = false;
+	for (;;)
+	{
+		if (!eof)
+		{
+			for (size_t k = 0; k < frames_per_turn && pos < S; k++)
+			{
+				const size_t n = std::min<size_t>(frame_size, S - pos);
+				put(pos, n);
+				pos += n;
+			}
+			// (the reference learns about the end of its input on the turn AFTER the last frame: try_pop fails and eof() is set)
+		}
+		if (mirror)
+		{
+			if (avail() > b.min_samples)
+				for (const size_t n : processor::cadence::drain(avail(), b.min_samples, b)) emit(n);
+			else if (eof)
+			{
+				flush();
+				for (const size_t n : processor::cadence::drain(avail(), 0, b)) emit(n);
+				break;
+			}
+		}
+		else
+		{
+			if (const size_t n = processor::cadence::reference_receive(avail(), b)) emit(n);
+			else if (eof)
+			{
+				flush();
+				if (avail() > 0) emit(avail());                      // ONE frame with everything that is left (:427-433)
+				break;
+			}
+		}
+		if (pos >= S && !eof && avail() <= b.min_samples) eof = true;   // an empty turn: the source has ended
+		else if (pos >= S && !eof && !mirror && processor::cadence::reference_receive(avail(), b) == 0) eof = true;
+	}
+	return c;
+}
+
+static Cadence oracle_cadence(const std::vector<float>& x, int frame_size, double rate, double pitch, float velocity, bool mirror, size_t frames_per_turn)
+{
+	orc_st* st = nullptr;
+	orc_st_create(48000, 2, rate, pitch, &st);
+	std::vector<float> sink;
+	Cadence c = run_cadence(
+		x.size() / 2, frame_size, velocity, mirror, frames_per_turn, [&](size_t pos, size_t n) { orc_st_put(st, x.data() + 2 * pos, n); },
+		[&] { return orc_st_available(st); },
+		[&](size_t n) { sink.resize(2 * n); return orc_st_receive(st, sink.data(), n); }, [&] { orc_st_flush(st); });
+	orc_st_destroy(st);
+	return c;
 }
 
 // ------------------------------------------------------------------------------------------------ CPU-only checks
@@ -494,6 +571,98 @@ static void test_gpu_pitch_soundtouch_algorithm()
 	CHECK(got.size() == ref.size() && std::equal(got.begin(), got.end(), ref.begin()), "soundtouch-algorithm output is bit-exact vs the oracle chain");
 }
 
+// every running node owns its context — the spectrum node too (it ran on the process-wide fallback context, so two
+// spectrum nodes of a graph shared one stream and waited for each other's work)
+static void test_gpu_two_spectrum_nodes_have_own_contexts()
+{
+	const int S = 20000;
+	Runner r;
+	auto src = std::make_shared<Test_source>();
+	src->samples = uniform(S * 2, 41);
+	auto spec_a = std::make_shared<Audio_spectrum>(), spec_b = std::make_shared<Audio_spectrum>();
+	auto sink_a = std::make_shared<Test_sink>(), sink_b = std::make_shared<Test_sink>();
+	r.add_node(1, src); r.add_node(2, spec_a); r.add_node(3, spec_b); r.add_node(4, sink_a); r.add_node(5, sink_b);
+	r.add_link({1, "output", 2, "input"});
+	r.add_link({1, "output", 3, "input"});
+	r.add_link({2, "output", 4, "input"});
+	r.add_link({3, "output", 5, "input"});
+	const size_t nodes_before = processor::gpu::flight_stats().nodes;
+	const bool ok = r.run();
+	CHECK(ok, "two spectrum nodes run: " << r.get_processor_resources().at(2)->error_text << r.get_processor_resources().at(3)->error_text);
+	if (!ok) return;
+	CHECK(spec_a->last_context != nullptr && spec_b->last_context != nullptr && spec_a->last_context != spec_b->last_context,
+		  "the two spectrum nodes ran on different contexts");
+	CHECK(processor::gpu::flight_stats().nodes == nodes_before + 2, "both are counted as GPU nodes");
+	const size_t F = orc_spectrum_frames(S);
+	std::vector<float> sref(F * 2 * 513);
+	orc_spectrum_f32(src->samples.data(), S, 2, sref.data());
+	for (const auto& sink : {sink_a, sink_b})
+	{
+		bool same = sink->frames.size() == F;
+		for (size_t f = 0; f < F && same; f++)
+			for (int c = 0; c < 2 && same; c++) same = std::memcmp(sink->frames[f]->data()->data[c], &sref[(f * 2 + c) * 513], 513 * sizeof(float)) == 0;
+		CHECK(same, "each spectrum node's frames are bit-exact vs the oracle");
+	}
+}
+
+// the pitch node's chunk sizes and time stamps (cadence): with frames arriving ONE AT A TIME the mirror emits the reference's own turn
+// sequence (audio-velocity.cpp:399-436 restated in run_cadence against the oracle's SoundTouch-shaped handle) up to the flush frame;
+// with frames arriving in batches the boundaries differ — the samples never do
+static void test_gpu_pitch_cadence()
+{
+	const int S = 120000;
+	const float semis = 3.0f;
+	const float p = std::pow(2.0f, semis / 12.0f);
+	const auto x = uniform((size_t)S * 2, 57);
+	const Cadence ref = oracle_cadence(x, 1152, 1.0, (double)p, 1.0f, false, 1);
+	for (int paced = 1; paced >= 0; paced--)
+	{
+		Runner r;
+		auto src = std::make_shared<Test_source>();
+		src->samples = x;
+		src->one_at_a_time = paced != 0;
+		auto pitch = std::make_shared<Pitch_modifier>();
+		Json::Value v;
+		v["pitch"] = (double)semis;
+		v["algorithm"] = "soundtouch";
+		pitch->deserialize(v);
+		auto sink = std::make_shared<Test_sink>();
+		sink->lazy_consumer = false;
+		r.add_node(1, src); r.add_node(2, pitch); r.add_node(3, sink);
+		r.add_link({1, "output", 2, "input"});
+		r.add_link({2, "output", 3, "input"});
+		const bool ok = r.run();
+		CHECK(ok, "cadence graph runs: " << r.get_processor_resources().at(2)->error_text);
+		if (!ok) return;
+		size_t total = 0, same = 0;
+		for (auto& f : sink->frames) total += (size_t)f->data()->nb_samples;
+		CHECK(total == ref.total, "cadence: " << total << " samples delivered, the reference's turns deliver " << ref.total);
+		while (same < ref.sizes.size() && same < sink->frames.size() && (size_t)sink->frames[same]->data()->nb_samples == ref.sizes[same] &&
+			   sink->frames[same]->data()->pts == ref.pts[same])
+			same++;
+		if (paced)
+			CHECK(same + 1 >= ref.sizes.size(), "frames arriving one at a time: the mirror's chunks and pts are the reference's up to the flush frame (" << same << " of "
+				  << ref.sizes.size() << ", " << pitch->batch_stats.rounds << " frames behind " << pitch->batch_stats.waits << " waits)");
+		else
+		{
+			const processor::cadence::Bounds b = processor::cadence::bounds(1.0f);
+			bool inside = true;
+			for (auto& f : sink->frames) inside = inside && (size_t)f->data()->nb_samples <= b.max_samples;
+			CHECK(inside && sink->frames.size() <= ref.sizes.size() + 2, "frames arriving in batches: chunks of at most max, no more frames than the reference's ("
+				  << sink->frames.size() << " vs " << ref.sizes.size() << ")");
+		}
+		// the float-typed microsecond clock: pts of frame k = float(sum of the samples in front of it / rate * 1e6)
+		double t = 0.0;
+		bool pts_ok = true;
+		for (auto& f : sink->frames)
+		{
+			pts_ok = pts_ok && f->data()->pts == (int64_t)(float)(t * 1000000);
+			t += double(f->data()->nb_samples) / 48000;
+		}
+		CHECK(pts_ok, "pts follow construct_audio_frame_float's float clock");
+	}
+}
+
 static void test_gpu_bimix_v2()
 {
 	const int S = 5000;
@@ -535,6 +704,51 @@ static void test_gpu_bimix_v2()
 
 // velocity_modifier / pitch_modifier nodes without an "algorithm" key (projects saved by the reference) follow the default the
 // integrator picked at registration; an explicit key wins; only a non-default choice is written back
+static void test_velocity_cadence_rules()
+{
+	using namespace processor::cadence;
+	// the rule itself (:416-423)
+	const Bounds b1 = bounds(1.0f), b2 = bounds(2.0f), bh = bounds(0.5f), b3 = bounds(1.5f);
+	CHECK(b1.min_samples == 1152 && b1.max_samples == 3456, "bounds at velocity 1");
+	CHECK(b2.min_samples == 576 && b2.max_samples == 1728, "bounds at velocity 2");
+	CHECK(bh.min_samples == 2304 && bh.max_samples == 6912, "bounds at velocity 0.5");
+	CHECK(b3.min_samples == (uint32_t)(double(1.0f / 1.5f) * 1152) && b3.max_samples == (uint32_t)(double(1.0f / 1.5f) * 1152 * 3), "bounds truncate the double product");
+	CHECK(reference_receive(1152, b1) == 0 && reference_receive(1153, b1) == 1153 && reference_receive(5000, b1) == 3456, "one turn's receive");
+	CHECK((drain(1152, 1152, b1).empty()) && (drain(8000, 1152, b1) == std::vector<size_t>{3456, 3456}) && (drain(8000, 0, b1) == std::vector<size_t>{3456, 3456, 1088}),
+		  "the mirror's turn = the rule until it no longer fires");
+	// the reference's turn sequence against the SoundTouch-shaped oracle handle, and the mirror's: frames one at a time give the SAME
+	// chunks and time stamps; batches of 16 give other boundaries, the same samples, sizes inside (min, max]
+	const int S = 200000;
+	const auto x = uniform((size_t)S * 2, 33);
+	struct Setting { double rate, pitch; float velocity; const char* name; };
+	const Setting settings[] = {{1.0, std::pow(2.0, 3.0 / 12.0), 1.0f, "pitch +3"}, {1.0, std::pow(2.0, -5.0 / 12.0), 1.0f, "pitch -5"},
+								{2.0, 0.5, 2.0f, "velocity 2 keep pitch"}, {0.5, 2.0, 0.5f, "velocity 0.5 keep pitch"}, {1.5, 1.0, 1.5f, "velocity 1.5"}};
+	for (const auto& st : settings)
+	{
+		const Bounds b = bounds(st.velocity);
+		const Cadence ref = oracle_cadence(x, 1152, st.rate, st.pitch, st.velocity, false, 1);
+		const Cadence one = oracle_cadence(x, 1152, st.rate, st.pitch, st.velocity, true, 1);
+		const Cadence bat = oracle_cadence(x, 1152, st.rate, st.pitch, st.velocity, true, 16);
+		CHECK(ref.total == one.total && ref.total == bat.total && ref.total > 0, st.name << ": all cadences deliver the same number of samples " << ref.total);
+		// everything in front of the flush: identical chunk for chunk (the flush remainder is ONE frame in the reference, <= max pieces in the mirror)
+		size_t same = 0;
+		while (same < ref.sizes.size() && same < one.sizes.size() && ref.sizes[same] == one.sizes[same] && ref.pts[same] == one.pts[same]) same++;
+		CHECK(same + 1 >= ref.sizes.size(), st.name << ": frames arriving one at a time -> the reference's chunks and pts up to the flush frame (" << same << " of "
+			  << ref.sizes.size() << " equal)");
+		size_t tail_ref = 0, tail_one = 0;
+		for (size_t k = same; k < ref.sizes.size(); k++) tail_ref += ref.sizes[k];
+		for (size_t k = same; k < one.sizes.size(); k++) tail_one += one.sizes[k];
+		CHECK(tail_ref == tail_one, st.name << ": the flush remainder holds the same samples");
+		bool inside = true;
+		for (size_t k = 0; k + 1 < bat.sizes.size(); k++) inside = inside && bat.sizes[k] <= b.max_samples && bat.sizes[k] > 0;
+		for (size_t k = 0; k < ref.sizes.size(); k++)
+			if (k + 1 < ref.sizes.size()) inside = inside && ref.sizes[k] > b.min_samples && ref.sizes[k] <= b.max_samples;
+		CHECK(inside, st.name << ": steady-state chunks lie in (min, max]");
+		// (the flush remainder, ONE frame in the reference, is cut into pieces of at most max by the mirror: up to two more frames there)
+		CHECK(bat.sizes.size() <= ref.sizes.size() + 2, st.name << ": batching makes larger chunks, not more frames (" << bat.sizes.size() << " vs " << ref.sizes.size() << ")");
+	}
+}
+
 static void test_default_stretch_algorithm()
 {
 	using namespace processor;
@@ -785,6 +999,7 @@ int main(int argc, char** argv)
 	test_registry_and_json();
 	test_bimix_align_step();
 	test_default_stretch_algorithm();
+	test_velocity_cadence_rules();
 	if (mode == "gpu")
 	{
 		test_error_capture();
@@ -794,6 +1009,8 @@ int main(int argc, char** argv)
 		test_gpu_pitch_spectrum_fanout();
 		test_gpu_velocity_keep_pitch();
 		test_gpu_pitch_soundtouch_algorithm();
+		test_gpu_pitch_cadence();
+		test_gpu_two_spectrum_nodes_have_own_contexts();
 		test_gpu_bimix_v1();
 		test_gpu_bimix_v2();
 	}

@@ -2,8 +2,8 @@
 // Every wave of the launch runs kIters x 256 instructions of one opcode on 16 rotating registers; the launch is timed with
 // hipEvents; TFLOP/s = wave-instructions x 64 lanes x flops per lane-op / seconds.  Beside it (a second figure, not the first
 // one's input): the shader clock the launch held, from s_memtime / s_memrealtime deltas of wave 0 of every workgroup.
-// Shapes: 256-thread workgroups (one wave per SIMD), W workgroups per CU for W = 1, 2, 4, 8 waves per SIMD, `rounds` rounds
-// of such a grid back to back in ONE launch (grid = n_cu x W x rounds) so that a launch lasts tens of milliseconds.
+// Shapes: 256-thread workgroups (one wave per SIMD); a dynamic-LDS request admits exactly W workgroups per CU (W = 1, 2, 4, 8
+// waves per SIMD); the grid is n_cu x W x rounds workgroups, so every CU works through `rounds` of them per slot.
 //   hipcc --offload-arch=gfx950 -O3 -o valu_wallclock valu_wallclock.hip && ./valu_wallclock > profiles/r05_valu_wallclock.md
 // Under rocprofv3 (--pmc SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU ...) pass "pmc" to run one launch per shape.
 #include <hip/hip_runtime.h>
@@ -23,8 +23,10 @@ struct Stamp { unsigned long long cyc0, cyc1, real0, real1; };
 template <int OP>
 __global__ __launch_bounds__(256) void stream_kernel(float* sink, Stamp* stamps, int iters, float b, float c)
 {
+    extern __shared__ float dyn_lds[];
     float a[16];
     float2 p[8];
+    if (iters < 0) dyn_lds[threadIdx.x] = b;               // (never: keeps the dynamic LDS request attached to the kernel)
 #pragma unroll
     for (int i = 0; i < 16; i++) a[i] = b * (float)(i + 1) + (float)threadIdx.x;
 #pragma unroll
@@ -83,16 +85,19 @@ int main(int argc, char** argv)
     printf("| opcode | waves per SIMD | rounds | ms per launch | TFLOP/s | clock GHz | cycles per wave-instr per SIMD | lanes retired per SIMD-cycle |\n|---|---|---|---|---|---|---|---|\n");
     for (int op = 0; op < N_OPS; op++) {
         for (int W : {1, 2, 4, 8}) {
-            const int rounds = 4;
+            const int rounds = W == 8 ? 2 : W == 4 ? 4 : W == 2 ? 8 : 16;
             const int iters = pmc ? 512 : 2048;
             const int blocks = n_cu * W * rounds;
+            // W workgroups fit a CU's 160 KiB, W + 1 do not (8: the wave slots limit)
+            const size_t lds_bytes = W == 1 ? 81 * 1024 : W == 2 ? 54 * 1024 : W == 4 ? 33 * 1024 : 0;
+            CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kKern[op]), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
             const double wave_instr = (double)blocks * 4 * iters * 256.0;
             std::vector<double> ms_all;
             double clock_ghz = 0;
             const int launches = pmc ? 1 : 6;
             for (int l = 0; l < launches; l++) {
                 CK(hipEventRecord(e0));
-                hipLaunchKernelGGL(kKern[op], dim3(blocks), dim3(256), 0, 0, sink, d_st, iters, 1.0000001f, 1e-9f);
+                hipLaunchKernelGGL(kKern[op], dim3(blocks), dim3(256), lds_bytes, 0, sink, d_st, iters, 1.0000001f, 1e-9f);
                 CK(hipEventRecord(e1));
                 CK(hipEventSynchronize(e1));
                 float ms; CK(hipEventElapsedTime(&ms, e0, e1));
