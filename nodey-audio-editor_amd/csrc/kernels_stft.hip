@@ -82,6 +82,7 @@ __global__ __launch_bounds__(kThreads, 4) void spectrum_kernel(SigViewD src, lon
 // that bypass L2 allocation — they are never read again by this kernel — another 0.1-0.3 ms.)
 constexpr int kSpecChunk = 32;         // frames one wave walks when the launch has many rounds of waves (16 / 64 / 128 measured
                                        // within 1 %: profiles/r02_spectrum_ablation.md); small batches: spec_pick_chunk
+constexpr int kSpecChunkFine = 8;      // frames of the short chunks at the end of a large launch's work list
 constexpr int kSpecStoreAux = 2;       // cache policy bits of the spectrum stores (2 = nt)
 constexpr size_t kLdsTablesPad = NAE_FFT_N * sizeof(float) + (kT1024Pad + 64 + kTwaCf) * sizeof(cf);
 constexpr size_t kLdsSpecStereo = kLdsTablesPad + kWaves * kPadScratchCf * sizeof(cf);
@@ -91,9 +92,26 @@ constexpr size_t kLdsSpecStereo = kLdsTablesPad + kWaves * kPadScratchCf * sizeo
 // per lane on 16-byte boundaries — four whole-wave 1-KiB pieces per frame instead of eighteen 256-byte dword pieces at every
 // 4-byte phase of a line (the shape tools/ubench/rw_mix.hip measures the chip's streaming rate with).  4104 = 8 mod 16: the 8
 // bytes by which a frame overhangs its last piece are carried in a register and go out with the next frame's first piece.
+// Work distribution.  The launch is PERSISTENT: at most two workgroups per CU (what fits), and every wave draws its next chunk of
+// consecutive frames from a device counter until the list is empty.  Round 5 measured why (tools/experiments/r05_spec_stamps.*): with
+// one chunk per wave and 14.75 rounds of workgroups per CU, the waves of a workgroup left its slot up to 20 % apart — 10 % of all
+// wave-slot time idle behind waves that had finished, 6 % more between workgroups.  The list is GUIDED: chunks of `chunk_c` frames for
+// the first `coarse_streams` streams, then chunks of `chunk_f` (short: a quarter of the re-read at a chunk's head, but the launch's tail is
+// one SHORT chunk long) for the rest.  Which wave computes which chunk does not touch any result.
+// counters[0]: next item; counters[1]: waves that have finished — the last one zeroes both, so the next launch on this context (same
+// stream: launches are ordered) starts from zero without a memset.
+struct SpecWork {
+    int chunk_c, chunk_f;
+    unsigned cps_c, cps_f;         // chunks per stream, coarse / fine
+    unsigned coarse_streams;
+    unsigned n_coarse;             // coarse items = coarse_streams * cps_c
+    unsigned n_items;
+    unsigned n_waves;              // waves of the launch
+    unsigned* counters;
+};
+
 template <bool kWide>
-__global__ __launch_bounds__(kThreads, 4) void spectrum_stereo_kernel(const float* __restrict__ src, long long src_ss, long long n_frames,
-                                                                     long long chunks_per_stream, int chunk, long long n_items,
+__global__ __launch_bounds__(kThreads, 4) void spectrum_stereo_kernel(const float* __restrict__ src, long long src_ss, long long n_frames, SpecWork work,
                                                                      float* __restrict__ dst, long long dst_ss, Tables tb)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -107,25 +125,24 @@ __global__ __launch_bounds__(kThreads, 4) void spectrum_stereo_kernel(const floa
     fill_twa(twa, tb.w512, threadIdx.x, kThreads);
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const long long item = (long long)blockIdx.x * kWaves + wave_id();
-    if (item >= n_items) return;
     cf* scratch = reinterpret_cast<cf*>(smem + kLdsTablesPad) + wave_id() * kPadScratchCf;
     const FftLds L = make_fft_lds(scratch, twa, w64, lane);
     const cf* hw = reinterpret_cast<const cf*>(hann) + lane;
     const cf* tsp = t1024 + lane;
     const cf* tspm = t1024 + 512 - lane;                       // split twiddles of the mirrors, [-64 r]
-    // (the 64-bit divisions run on the vector ALU: bring the wave-uniform results back to scalar registers)
-    const int s = __builtin_amdgcn_readfirstlane((int)(item / chunks_per_stream));
-    const int f0 = __builtin_amdgcn_readfirstlane((int)(item % chunks_per_stream)) * chunk;
-    const int f1 = f0 + chunk > (int)n_frames ? (int)n_frames : f0 + chunk;
-    const float* sbase = src + (long long)s * src_ss + 4 * lane;   // frames lie fully inside [0, T) by construction
-    float* obase = dst + (long long)s * dst_ss;
+    // the chunk this wave works on (wave-uniform; set per drawn item)
+    int s = 0, f0 = 0, f1 = 0;
+    const float* sbase = src;
+    float* obase = dst;
+    long long gbase = 0;
+    unsigned drawn = 0;                                        // lane 0: the item number the counter handed out
+    auto draw = [&]() { if (lane == 0) drawn = atomicAdd(&work.counters[0], 1u); };
+    draw();
     // magnitudes of one channel: [0..3] bins lane + 64 r, [4..7] their mirrors 512 - lane - 64 r, [8] bin 256 (lane 0)
     float ma[9], mb[9];
     typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
     typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
     float carry = 0.0f;                  // kWide: mb[4] of the frame staged last = bin 512 (lane 0) / 511 (lane 1) of its second channel
-    const long long gbase = (long long)s * dst_ss;
     // LDS byte offset of the wave's scratch (wave-uniform) for ds_write_addtid_b32: address = M0 + offset + 4 * lane without an address
     // VGPR — half the cycles of ds_write_b32 on gfx950 (MI355X_MICROARCH.md, LDS).  The lane-ascending halves go that way.
     const unsigned scratch_off = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)scratch);
@@ -224,12 +241,31 @@ __global__ __launch_bounds__(kThreads, 4) void spectrum_stereo_kernel(const floa
     // consecutive frames overlap by 768 of 1024 sample-frames = 6 of the 8 rows of the FFT input layout (pair index
     // n = lane + 64 j, hop = 128 pairs = 2 rows): the raw samples stay in registers and a frame loads only its last 2 rows,
     // so every input byte is read once
+#pragma unroll 1
+    for (;;) {
+    const unsigned item = (unsigned)__builtin_amdgcn_readfirstlane((int)drawn);
+    if (item >= work.n_items) break;
+    {
+        // (the divisions run on the vector ALU once per chunk: bring the wave-uniform results back to scalar registers)
+        unsigned sv, kv;
+        int ck;
+        if (item < work.n_coarse) { sv = item / work.cps_c; kv = item - sv * work.cps_c; ck = work.chunk_c; }
+        else { const unsigned j = item - work.n_coarse; const unsigned q = j / work.cps_f; sv = work.coarse_streams + q; kv = j - q * work.cps_f; ck = work.chunk_f; }
+        s = __builtin_amdgcn_readfirstlane((int)sv);
+        const int chunk = __builtin_amdgcn_readfirstlane(ck);
+        f0 = __builtin_amdgcn_readfirstlane((int)kv) * chunk;
+        f1 = f0 + chunk > (int)n_frames ? (int)n_frames : f0 + chunk;
+        sbase = src + (long long)s * src_ss + 4 * lane;            // frames lie fully inside [0, T) by construction
+        obase = dst + (long long)s * dst_ss;
+        gbase = (long long)s * dst_ss;
+    }
     float4 raw[8], pre[2];
     if (f0 < f1) {
         const float* base = sbase + 2 * ((long long)f0 * NAE_HOP);
 #pragma unroll
         for (int j = 0; j < 8; j++) raw[j] = *reinterpret_cast<const float4*>(base + 256 * j);
     }
+    draw();                                                        // the next item: its latency hides behind this chunk
 #pragma unroll 1
     for (int f = f0; f < f1; f++) {
         cf v0[8], v1[8];
@@ -274,8 +310,18 @@ __global__ __launch_bounds__(kThreads, 4) void spectrum_stereo_kernel(const floa
             for (int i = 0; i < 4; i++) q[i] = stq[64 * i];
             q[4] = stq[256];
             emit_frame(f1 - 1, q, f1 - 1 == f0, true);
+            wave_lds_sync();
         }
         else store_frame(f1 - 1);
+    }
+    }   // next chunk
+    if (lane == 0) {
+        // this wave's last draw has returned (it is what ended the loop): once every wave of the launch has said so, nobody touches
+        // the counters any more and the last one resets them for the next launch
+        if (atomicAdd(&work.counters[1], 1u) + 1u == work.n_waves) {
+            atomicExch(&work.counters[0], 0u);
+            atomicExch(&work.counters[1], 0u);
+        }
     }
 }
 
@@ -861,18 +907,45 @@ int nae_launch_spectrum(nae_ctx* ctx, const nae_sig* src, size_t T, int ch, size
     const bool stereo_fast = ch == 2 && src->chan_stride == 1 && src->frame_stride == 2 && src->stream_stride % 4 == 0 &&
                              (reinterpret_cast<uintptr_t>(src->base) & 15) == 0 && !ctx->dbg_spec_generic;
     if (stereo_fast) {
-        const int chunk = ctx->dbg_spec_chunk > 0 ? ctx->dbg_spec_chunk : spec_pick_chunk((long long)F, (long long)n_streams, ctx->n_cu);
-        const long long chunks = ((long long)F + chunk - 1) / chunk;
-        const long long citems = chunks * (long long)n_streams;
+        const long long slots = (long long)ctx->n_cu * 16;                   // waves a launch keeps resident (two workgroups per CU)
+        SpecWork w{};
+        w.counters = ctx->d_spec_ctr;
+        const long long coarse_all = (((long long)F + kSpecChunk - 1) / kSpecChunk) * (long long)n_streams;
+        if (ctx->dbg_spec_chunk > 0 || coarse_all < 6 * slots) {
+            // small batch (or a forced chunk): one list of equal chunks, sized so that the waves fill a whole number of rounds
+            w.chunk_c = ctx->dbg_spec_chunk > 0 ? ctx->dbg_spec_chunk : spec_pick_chunk((long long)F, (long long)n_streams, ctx->n_cu);
+            w.cps_c = (unsigned)(((long long)F + w.chunk_c - 1) / w.chunk_c);
+            w.coarse_streams = (unsigned)n_streams;
+            w.chunk_f = w.chunk_c;
+            w.cps_f = w.cps_c;
+        } else {
+            // large batch: 32-frame chunks, and 8-frame chunks for the last streams — about four short chunks per resident wave, at most an
+            // eighth of the job — so that the launch ends within one short chunk
+            w.chunk_c = kSpecChunk;
+            w.cps_c = (unsigned)(((long long)F + kSpecChunk - 1) / kSpecChunk);
+            w.chunk_f = kSpecChunkFine;
+            w.cps_f = (unsigned)(((long long)F + kSpecChunkFine - 1) / kSpecChunkFine);
+            long long fine_streams = (4 * slots + w.cps_f - 1) / w.cps_f;
+            if (fine_streams > (long long)n_streams / 8) fine_streams = (long long)n_streams / 8;
+            w.coarse_streams = (unsigned)((long long)n_streams - fine_streams);
+        }
+        const long long n_coarse = (long long)w.coarse_streams * w.cps_c;
+        const long long items = n_coarse + ((long long)n_streams - w.coarse_streams) * w.cps_f;
+        if (items > 0x7fffffffll) return nae_fail(ctx, NAE_ERR_INVALID, "spectrum_stereo_kernel: too many chunks");
+        w.n_coarse = (unsigned)n_coarse;
+        w.n_items = (unsigned)items;
+        long long groups = (items + kWaves - 1) / kWaves;
+        if (groups > 2ll * ctx->n_cu) groups = 2ll * ctx->n_cu;
+        w.n_waves = (unsigned)(groups * kWaves);
         const bool wide = (reinterpret_cast<uintptr_t>(dst) & 15) == 0 && dst_stream_stride % 2 == 0 && !ctx->dbg_spec_narrow;
         if (wide)
-            NAE_KLAUNCH(ctx, "spectrum_stereo_kernel", spectrum_stereo_kernel<true>, dim3((unsigned)((citems + kWaves - 1) / kWaves)), dim3(kThreads),
+            NAE_KLAUNCH(ctx, "spectrum_stereo_kernel", spectrum_stereo_kernel<true>, dim3((unsigned)groups), dim3(kThreads),
                         kLdsSpecStereo, ctx->stream, static_cast<const float*>(src->base), (long long)src->stream_stride,
-                        (long long)F, chunks, chunk, citems, dst, (long long)dst_stream_stride, tb);
+                        (long long)F, w, dst, (long long)dst_stream_stride, tb);
         else
-            NAE_KLAUNCH(ctx, "spectrum_stereo_kernel", spectrum_stereo_kernel<false>, dim3((unsigned)((citems + kWaves - 1) / kWaves)), dim3(kThreads),
+            NAE_KLAUNCH(ctx, "spectrum_stereo_kernel", spectrum_stereo_kernel<false>, dim3((unsigned)groups), dim3(kThreads),
                         kLdsSpecStereo, ctx->stream, static_cast<const float*>(src->base), (long long)src->stream_stride,
-                        (long long)F, chunks, chunk, citems, dst, (long long)dst_stream_stride, tb);
+                        (long long)F, w, dst, (long long)dst_stream_stride, tb);
     }
     else if (src->frame_stride == 1)
         NAE_KLAUNCH(ctx, "spectrum_kernel", (spectrum_kernel<true>), dim3(grid), dim3(kThreads), lds, ctx->stream, to_view(src),

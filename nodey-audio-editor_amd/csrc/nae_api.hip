@@ -235,7 +235,8 @@ int nae_ctx_create(int device, nae_ctx** out)
     build_tables(w512, t1024, hann);
     bool ok = hipMalloc((void**)&ctx->d_w512, 512 * sizeof(nae::cf)) == hipSuccess &&
               hipMalloc((void**)&ctx->d_t1024, 520 * sizeof(nae::cf)) == hipSuccess &&
-              hipMalloc((void**)&ctx->d_hann, 1024 * sizeof(float)) == hipSuccess;
+              hipMalloc((void**)&ctx->d_hann, 1024 * sizeof(float)) == hipSuccess &&
+              hipMalloc((void**)&ctx->d_spec_ctr, 64) == hipSuccess && hipMemset(ctx->d_spec_ctr, 0, 64) == hipSuccess;
     ok = ok && hipMemcpy(ctx->d_w512, w512.data(), 512 * sizeof(nae::cf), hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(ctx->d_t1024, t1024.data(), 513 * sizeof(nae::cf), hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(ctx->d_hann, hann.data(), 1024 * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
@@ -253,6 +254,7 @@ int nae_ctx_destroy(nae_ctx* ctx)
     if (ctx->d_w512) (void)hipFree(ctx->d_w512);
     if (ctx->d_t1024) (void)hipFree(ctx->d_t1024);
     if (ctx->d_hann) (void)hipFree(ctx->d_hann);
+    if (ctx->d_spec_ctr) (void)hipFree(ctx->d_spec_ctr);
     if (ctx->d_rs_tab) (void)hipFree(ctx->d_rs_tab);
     if (ctx->ws_phase) (void)hipFree(ctx->ws_phase);
     if (ctx->ws_mid) (void)hipFree(ctx->ws_mid);

@@ -14,10 +14,23 @@ def rep(a, b, count=1):
     assert s.count(a) >= 1, a
     s = s.replace(a, b, count)
 # the kernel template is instantiated twice; the stamps only make sense in the wide path but compile in both
+rep('''    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* hann = reinterpret_cast<float*>(smem);
+    cf* t1024 = reinterpret_cast<cf*>(smem + NAE_FFT_N * sizeof(float));
+    cf* w64 = t1024 + kT1024Pad;
+    cf* twa = w64 + 64;
+    for (int i = threadIdx.x; i < NAE_FFT_N; i += kThreads) hann[i] = tb.hann[i];''', '''    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned long long t_entry = __builtin_readcyclecounter(), r_entry = __builtin_amdgcn_s_memrealtime();
+    float* hann = reinterpret_cast<float*>(smem);
+    cf* t1024 = reinterpret_cast<cf*>(smem + NAE_FFT_N * sizeof(float));
+    cf* w64 = t1024 + kT1024Pad;
+    cf* twa = w64 + 64;
+    for (int i = threadIdx.x; i < NAE_FFT_N; i += kThreads) hann[i] = tb.hann[i];''', 2)
 rep('''#pragma unroll 1
     for (int f = f0; f < f1; f++) {
         cf v0[8], v1[8];
-        u32x4 q[5];''', '''    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+        u32x4 q[5];''', '''    const unsigned long long t_loop0 = __builtin_readcyclecounter();
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
     auto STAMP = [&](int i) { const unsigned long long t = __builtin_readcyclecounter(); tacc[i] += t - tprev; tprev = t; };
 #pragma unroll 1
     for (int f = f0; f < f1; f++) {
@@ -55,11 +68,18 @@ rep('''        else store_frame(f1 - 1);
     }
 }''', '''        else store_frame(f1 - 1);
     }
-    if (f1 > f0 && lane < 6) {
+    if (f1 > f0 && lane < 12) {
         unsigned long long* o = reinterpret_cast<unsigned long long*>(obase + (long long)f0 * (2 * NAE_FFT_BINS));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t_exit = __builtin_readcyclecounter();
         unsigned long long v = tacc[0];
         for (int i = 1; i < 6; i++) v = lane == i ? tacc[i] : v;
+        if (lane == 6) v = t_loop0 - t_entry;          // prologue: table fill, barrier, first frame's loads issued
+        if (lane == 7) v = tprev - t_loop0;            // the loop
+        if (lane == 8) v = t_exit - tprev;             // epilogue: last frame's stores
+        if (lane == 9) v = t_entry;                    // absolute entry time (per-XCD counter)
+        if (lane == 10) v = r_entry;                   // 100 MHz wall clock at entry
+        if (lane == 11) v = __builtin_amdgcn_s_memrealtime();   // ... at exit
         o[lane] = v;
     }
 }''')
