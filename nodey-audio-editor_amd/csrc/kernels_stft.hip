@@ -98,8 +98,9 @@ constexpr size_t kLdsSpecStereo = kLdsTablesPad + kWaves * kPadScratchCf * sizeo
 // wave-slot time idle behind waves that had finished, 6 % more between workgroups.  The list is GUIDED: chunks of `chunk_c` frames for
 // the first `coarse_streams` streams, then chunks of `chunk_f` (short: a quarter of the re-read at a chunk's head, but the launch's tail is
 // one SHORT chunk long) for the rest.  Which wave computes which chunk does not touch any result.
-// counters[0]: next item; counters[1]: waves that have finished — the last one zeroes both, so the next launch on this context (same
-// stream: launches are ordered) starts from zero without a memset.
+// A wave's FIRST item is the one of its position in the grid (no atomic: 4096 waves drawing from one address at the same moment cost a
+// small batch 0.15 ms); item n_waves + counters[0]++ comes next.  counters[1]: waves that have finished — the last one zeroes both, so the
+// next launch on this context (same stream: launches are ordered) starts from zero without a memset.
 struct SpecWork {
     int chunk_c, chunk_f;
     unsigned cps_c, cps_f;         // chunks per stream, coarse / fine
@@ -107,6 +108,7 @@ struct SpecWork {
     unsigned n_coarse;             // coarse items = coarse_streams * cps_c
     unsigned n_items;
     unsigned n_waves;              // waves of the launch
+    unsigned dynamic;              // 0: no more items than waves — every wave works on the item of its position and nobody touches the counters
     unsigned* counters;
 };
 
@@ -135,9 +137,9 @@ __global__ __launch_bounds__(kThreads, 4) void spectrum_stereo_kernel(const floa
     const float* sbase = src;
     float* obase = dst;
     long long gbase = 0;
-    unsigned drawn = 0;                                        // lane 0: the item number the counter handed out
+    unsigned drawn = 0;                                        // lane 0: what the counter handed out
     auto draw = [&]() { if (lane == 0) drawn = atomicAdd(&work.counters[0], 1u); };
-    draw();
+    unsigned item = blockIdx.x * kWaves + (unsigned)wave_id();
     // magnitudes of one channel: [0..3] bins lane + 64 r, [4..7] their mirrors 512 - lane - 64 r, [8] bin 256 (lane 0)
     float ma[9], mb[9];
     typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -243,7 +245,6 @@ __global__ __launch_bounds__(kThreads, 4) void spectrum_stereo_kernel(const floa
     // so every input byte is read once
 #pragma unroll 1
     for (;;) {
-    const unsigned item = (unsigned)__builtin_amdgcn_readfirstlane((int)drawn);
     if (item >= work.n_items) break;
     {
         // (the divisions run on the vector ALU once per chunk: bring the wave-uniform results back to scalar registers)
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(kThreads, 4) void spectrum_stereo_kernel(const floa
 #pragma unroll
         for (int j = 0; j < 8; j++) raw[j] = *reinterpret_cast<const float4*>(base + 256 * j);
     }
-    draw();                                                        // the next item: its latency hides behind this chunk
+    if (work.dynamic) draw();                                      // the next item: its latency hides behind this chunk
 #pragma unroll 1
     for (int f = f0; f < f1; f++) {
         cf v0[8], v1[8];
@@ -314,8 +315,10 @@ __global__ __launch_bounds__(kThreads, 4) void spectrum_stereo_kernel(const floa
         }
         else store_frame(f1 - 1);
     }
+    if (!work.dynamic) break;
+    item = work.n_waves + (unsigned)__builtin_amdgcn_readfirstlane((int)drawn);
     }   // next chunk
-    if (lane == 0) {
+    if (work.dynamic && lane == 0) {
         // this wave's last draw has returned (it is what ended the loop): once every wave of the launch has said so, nobody touches
         // the counters any more and the last one resets them for the next launch
         if (atomicAdd(&work.counters[1], 1u) + 1u == work.n_waves) {
@@ -937,6 +940,7 @@ int nae_launch_spectrum(nae_ctx* ctx, const nae_sig* src, size_t T, int ch, size
         long long groups = (items + kWaves - 1) / kWaves;
         if (groups > 2ll * ctx->n_cu) groups = 2ll * ctx->n_cu;
         w.n_waves = (unsigned)(groups * kWaves);
+        w.dynamic = items > groups * kWaves ? 1u : 0u;
         const bool wide = (reinterpret_cast<uintptr_t>(dst) & 15) == 0 && dst_stream_stride % 2 == 0 && !ctx->dbg_spec_narrow;
         if (wide)
             NAE_KLAUNCH(ctx, "spectrum_stereo_kernel", spectrum_stereo_kernel<true>, dim3((unsigned)groups), dim3(kThreads),
