@@ -914,8 +914,8 @@ int nae_launch_spectrum(nae_ctx* ctx, const nae_sig* src, size_t T, int ch, size
         SpecWork w{};
         w.counters = ctx->d_spec_ctr;
         const long long coarse_all = (((long long)F + kSpecChunk - 1) / kSpecChunk) * (long long)n_streams;
-        if (ctx->dbg_spec_chunk > 0 || coarse_all < 6 * slots) {
-            // small batch (or a forced chunk): one list of equal chunks, sized so that the waves fill a whole number of rounds
+        if (coarse_all < 6 * slots) {
+            // small batch: one list of equal chunks, sized so that the waves fill a whole number of rounds
             w.chunk_c = ctx->dbg_spec_chunk > 0 ? ctx->dbg_spec_chunk : spec_pick_chunk((long long)F, (long long)n_streams, ctx->n_cu);
             w.cps_c = (unsigned)(((long long)F + w.chunk_c - 1) / w.chunk_c);
             w.coarse_streams = (unsigned)n_streams;
@@ -924,11 +924,11 @@ int nae_launch_spectrum(nae_ctx* ctx, const nae_sig* src, size_t T, int ch, size
         } else {
             // large batch: 32-frame chunks, and 8-frame chunks for the last streams — about four short chunks per resident wave, at most an
             // eighth of the job — so that the launch ends within one short chunk
-            w.chunk_c = kSpecChunk;
-            w.cps_c = (unsigned)(((long long)F + kSpecChunk - 1) / kSpecChunk);
-            w.chunk_f = kSpecChunkFine;
-            w.cps_f = (unsigned)(((long long)F + kSpecChunkFine - 1) / kSpecChunkFine);
-            long long fine_streams = (4 * slots + w.cps_f - 1) / w.cps_f;
+            w.chunk_c = ctx->dbg_spec_chunk > 0 ? ctx->dbg_spec_chunk : kSpecChunk;
+            w.cps_c = (unsigned)(((long long)F + w.chunk_c - 1) / w.chunk_c);
+            w.chunk_f = ctx->dbg_spec_fine > 0 ? ctx->dbg_spec_fine : kSpecChunkFine;
+            w.cps_f = (unsigned)(((long long)F + w.chunk_f - 1) / w.chunk_f);
+            long long fine_streams = ((ctx->dbg_spec_fine_rounds > 0 ? ctx->dbg_spec_fine_rounds : 4) * slots + w.cps_f - 1) / w.cps_f;
             if (fine_streams > (long long)n_streams / 8) fine_streams = (long long)n_streams / 8;
             w.coarse_streams = (unsigned)((long long)n_streams - fine_streams);
         }

@@ -230,6 +230,8 @@ int nae_ctx_create(int device, nae_ctx** out)
     ctx->dbg_spec_narrow = getenv("NAE_SPEC_NARROW") != nullptr;
     ctx->pv_lean = getenv("NAE_PV_LEAN") != nullptr;
     if (const char* e = getenv("NAE_SPEC_CHUNK")) ctx->dbg_spec_chunk = atoi(e);
+    if (const char* e = getenv("NAE_SPEC_FINE")) ctx->dbg_spec_fine = atoi(e);
+    if (const char* e = getenv("NAE_SPEC_FINE_ROUNDS")) ctx->dbg_spec_fine_rounds = atoi(e);
     std::vector<nae::cf> w512, t1024;
     std::vector<float> hann;
     build_tables(w512, t1024, hann);
