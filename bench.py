@@ -331,8 +331,8 @@ def main():
             "pitch_node_ms": round(w_ms, 3), "kernels_avg_ms": wk, "sequences_per_stream": int(wpl.n_seq),
             "graph_sample_frames_per_s": n_streams * S / ((w_ms + other) * 1e-3)}
         # what binds the two kernels: vector issue at the measured interval + LDS-array cycles against the kernel's cycles, from the
-        # rocprofv3 --pmc passes of this build with the WSOLA leg in the run (ALT=1 tools/pmc_sq.sh -> profiles/r04_wsola_sq.md)
-        wpath = os.path.join(ROOT, "profiles", "r04_wsola_traffic.json")
+        # rocprofv3 --pmc passes of this build with the WSOLA leg in the run (ALT=1 tools/pmc_sq.sh -> profiles/r05_wsola_sq.md)
+        wpath = os.path.join(ROOT, "profiles", "r05_wsola_traffic.json")
         wdata = json.load(open(wpath)) if os.path.exists(wpath) else {}
         valu = {}
         for kname, avg_ms in wk.items():

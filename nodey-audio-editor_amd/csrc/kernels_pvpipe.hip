@@ -1,7 +1,8 @@
 // kernels_pvpipe.hip — pass 3 of the phase vocoder (K7) as a four-role wave pipeline for gfx950.
 //
-// Why a pipeline.  On gfx950 one wave issues at most one vector instruction per 4.5-5 cycles, while a SIMD with 8 resident
-// waves issues one per 1.0-1.3 cycles (profiles/r02_valu_issue.md).  A stream-channel of the vocoder is a serial chain of
+// Why a pipeline.  On gfx950 one wave issues at most one vector instruction per 4.5-5 cycles, while a SIMD with two or more
+// resident waves retires one per 2.15 cycles (profiles/r05_valu_wallclock.md; rounds 2-4 believed 1.0-1.3 at 8 waves) — and more
+// waves hide the LDS round trips and barrier waits.  A stream-channel of the vocoder is a serial chain of
 // frames (integer phase accumulator, overlap-add), so "one wave per stream-channel" leaves most issue slots empty.  Here a
 // frame passes through FOUR waves, one per role, that hand it on through LDS once per step, and every role fits 64 VGPRs:
 // a 1024-thread workgroup is 4 slots x 4 roles, two workgroups fill a CU (32 waves, 8 per SIMD — each SIMD hosts one wave

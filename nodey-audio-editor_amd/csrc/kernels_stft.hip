@@ -318,7 +318,7 @@ __global__ __launch_bounds__(kThreads, 4) void spectrum_stereo_kernel(const floa
     if (!work.dynamic) break;
     item = work.n_waves + (unsigned)__builtin_amdgcn_readfirstlane((int)drawn);
     }   // next chunk
-    if (work.dynamic && lane == 0) {
+    if (work.dynamic && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) {    // lane 0, recomputed: `lane` is not kept alive across the chunk loop
         // this wave's last draw has returned (it is what ended the loop): once every wave of the launch has said so, nobody touches
         // the counters any more and the last one resets them for the next launch
         if (atomicAdd(&work.counters[1], 1u) + 1u == work.n_waves) {

@@ -135,9 +135,8 @@ __device__ __forceinline__ void fft512_fwd(cf (&v)[8], cf* __restrict__ scratch,
 // (MI355X_MICROARCH.md §LDS): 72 = 8 mod 32 and 66 = 2 mod 16 make each group hit distinct banks.
 // Scratch: 576 complex (4608 B) per wave; natural order [lane + 64 r] (+ one entry at 512) uses the same area.
 // What it buys: the FFT alone fits 45 VGPRs (the round-1 form with hoisted swizzle addresses and twiddles in registers
-// needed ~100), so a kernel built on it can keep 6 waves per SIMD resident — and on gfx950 the vector issue rate of a
-// SIMD grows with resident waves up to 8 (profiles/r02_valu_issue.md: one wave alone issues one instruction per 4.5-5
-// cycles, eight waves together one per 1.0-1.4).  Measured alone (profiles/r02_fftpad.md): 141-155 cycles of a CU per
+// needed ~100), so a kernel built on it can keep 6 waves per SIMD resident — one wave alone issues one vector instruction per 4.5-5
+// cycles, two or more together one per 2.15 (profiles/r05_valu_wallclock.md), and the further waves hide LDS round trips.  Measured alone (profiles/r02_fftpad.md): 141-155 cycles of a CU per
 // FFT at 6-8 waves per SIMD, LDS-bound (16 ds_write_b64 at 3.8 cycles + 30 ds_read_b64 at 1.3 cycles of the CU's LDS pipe).
 constexpr int kPadScratchCf = 576;
 constexpr int kTwaCf = 7 * 64;                   // LDS table W512^(lane q), q = 1..7, laid out [q-1][lane]
