@@ -53,6 +53,72 @@ def test_k8_stereo_batched_layouts_and_edges(ctx, nae):
     assert gpu_spectrum(ctx, nae, orc.fill_uniform(1024, 1), 1).shape == (1, 1, 1, 513)
 
 
+def test_k8_wide_stores_every_alignment_case(ctx, nae):
+    """the stereo kernel writes a frame's 4104 bytes as 16-byte line-aligned pieces when the destination allows it: an ODD frame count
+    makes the streams alternate between the two 16-byte phases (a chunk that starts on the odd phase writes its first 8 bytes alone, one
+    that ends on the even phase its last 8), a destination that is only 8-byte aligned or has an odd stream stride takes the dword
+    pieces; every case is bit-identical to the oracle and leaves the bytes around the result untouched"""
+    n_streams, T = 7, 1024 + 256 * 12 + 3                      # 13 frames per stream
+    F = ctx.spectrum_frames(T)
+    assert F == 13
+    x = orc.fill_uniform(n_streams * T * 2, 32)
+    ref = np.stack([orc.spectrum(x.reshape(n_streams, -1)[s], 2) for s in range(n_streams)])
+    d_x = ctx.array(x)
+    sig = nae.Sig.interleaved(d_x.ptr, T, 2)
+    n = F * 2 * 513
+    for lead, stride in ((0, n), (2, n), (0, n + 1), (4, n + 2), (1, n)):     # floats in front of the result / stream stride
+        guard = np.float32(-7.0)
+        total = lead + n_streams * stride + 8
+        d_o = ctx.array(np.full(total, guard, np.float32))
+        ctx.spectrum_block(sig, T, 2, n_streams, d_o.at(lead), stride)
+        out = d_o.download()
+        d_o.free()
+        for st in range(n_streams):
+            got = out[lead + st * stride: lead + st * stride + n].reshape(F, 2, 513)
+            assert np.array_equal(got.view(np.uint32), ref[st].view(np.uint32)), (lead, stride, st)
+            if stride > n:
+                assert (out[lead + st * stride + n: lead + (st + 1) * stride] == guard).all(), "the gap between two streams is untouched"
+        assert (out[:lead] == guard).all() and (out[lead + n_streams * stride:] == guard).all(), "nothing written outside the result"
+    d_x.free()
+
+
+def test_k8_guided_chunk_list_equals_the_generic_kernel(ctx, nae):
+    """a large batch runs the persistent launch: 32-frame chunks, 8-frame chunks for the last streams, every chunk but a wave's first
+    drawn from a device counter that the launch's last wave resets.  8200 streams x 77 frames (odd: both store phases, a 13-frame tail chunk)
+    against the one-wave-per-frame generic kernel on a second context, compared on the device; twice in a row (the counter must be back at
+    zero), and three streams against the oracle"""
+    import os
+    n_streams, F = 8200, 77
+    T = 1024 + 256 * (F - 1)
+    n = F * 2 * 513
+    d_x, d_a, d_b = ctx.empty(n_streams * T * 2), ctx.empty(n_streams * n), ctx.empty(n_streams * n)
+    ctx.fill_uniform(d_x.ptr, T * 2, T * 2, n_streams, 0, 0)
+    sig = nae.Sig.interleaved(d_x.ptr, T, 2)
+    os.environ["NAE_SPEC_GENERIC"] = "1"
+    try:
+        with nae.Context(0) as generic:
+            generic.spectrum_block(sig, T, 2, n_streams, d_b.ptr, n)
+            generic.sync()
+    finally:
+        del os.environ["NAE_SPEC_GENERIC"]
+    d_cnt = ctx.array(np.zeros(2, np.uint64))
+    for rep in range(2):
+        ctx._ck(ctx.lib.nae_memset(ctx.h, d_a.ptr, 0xFF, n_streams * n * 4))
+        ctx.spectrum_block(sig, T, 2, n_streams, d_a.ptr, n)
+        ctx.diff_words(d_a.ptr, d_b.ptr, n_streams * n, d_cnt.at(rep))
+    ctx.sync()
+    assert d_cnt.download().tolist() == [0, 0], "words differing between the persistent stereo kernel and the generic one (first, second launch)"
+    for st in (0, 4100, 8199):
+        xs = np.empty(T * 2, np.float32)
+        ctx._ck(ctx.lib.nae_memcpy_d2h(ctx.h, xs.ctypes.data, d_x.at(st * T * 2), xs.nbytes))
+        got = np.empty(n, np.float32)
+        ctx._ck(ctx.lib.nae_memcpy_d2h(ctx.h, got.ctypes.data, d_a.at(st * n), got.nbytes))
+        ctx.sync()
+        assert np.array_equal(got.view(np.uint32), orc.spectrum(xs, 2).reshape(-1).view(np.uint32)), st
+    for d in (d_x, d_a, d_b, d_cnt):
+        d.free()
+
+
 @pytest.mark.parametrize("planar", [False, True])
 def test_k8_non_finite_samples_stay_in_their_frames(ctx, nae, planar):
     """one NaN and one Inf sample in the left channel: exactly the frames whose window covers them are non-finite (as in the
