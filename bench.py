@@ -131,6 +131,7 @@ def main():
         if rank == 0:
             ctx.fill_uniform(t_b.data_ptr(), S * 2, 0, 1, 0, 1)
             ctx.sync()
+        shard.broadcast_shared(dist, torch.zeros(1, dtype=torch.float32, device=f"cuda:{local_rank}"), 0)   # untimed: creates the RCCL communicator
         bcast_ms, bcast_bytes = shard.timed_broadcast_shared(dist, t_b, 0, sync=torch.cuda.synchronize)
         b_ptr = t_b.data_ptr()
     else:
