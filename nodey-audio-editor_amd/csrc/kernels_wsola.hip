@@ -103,10 +103,15 @@ __device__ __forceinline__ Best better(Best a, Best b)
 
 __device__ unsigned g_td_arrivals[8 * 4 * 16];
 
-template <int CH, int NC>
-__global__ __launch_bounds__(1024 / NC, 4) void st_td_kernel(DView in, TdParams p, DOut out, float* __restrict__ mid_state,
+// KS: the LDS row stride as a compile-time value (0: p.S at run time).  With it the eight rows a search trip reads sit at immediate offsets of ONE
+// address register instead of eight registers that are each advanced per trip: 7 of a trip's 229 vector instructions (round 5; instantiated for the
+// stereo 48-kHz geometry — overlap 384 frames — that BASELINE.json's configs run).
+template <int CH, int NC, int KS = 0>
+__global__ __launch_bounds__(1024 / NC, 4) void st_td_kernel(DView in, TdParams p_in, DOut out, float* __restrict__ mid_state,
                                                          int32_t* __restrict__ offs_dbg, long long offs_stride)
 {
+    TdParams p = p_in;
+    if (KS != 0) p.S = KS;
     using G = TdGeo<CH, NC>;
     constexpr int T = G::THREADS;
     extern __shared__ __attribute__((aligned(16))) float td_smem[];
@@ -254,9 +259,19 @@ __global__ __launch_bounds__(1024 / NC, 4) void st_td_kernel(DView in, TdParams 
                         const int Gs = NC * g + e;
                         float X[4], Q[4];
 #pragma unroll
-                        for (int m = 0; m < G::P; m++)
+                        for (int m = 0; m < G::P; m++) {
+                            if (CH == 2 && KS != 0) {
+                                // one 8-byte read per stereo frame at an IMMEDIATE offset of the trip's one address register (ds_read_b64 takes 16 bits of
+                                // offset; the ds_read2_b32 the compiler picks for two floats of unknown alignment only 8 bits of dwords)
+                                typedef __attribute__((address_space(3))) const volatile unsigned long long lds_u64;   // volatile: two of them must not be paired into a ds_read2_b64 (twice the LDS time per byte)
+                                const unsigned long long u = *(lds_u64*)(xrow + ((G::P * e + m) * KS + g) * 2);
+                                X[m * 2] = __uint_as_float((unsigned)u);
+                                X[m * 2 + 1] = __uint_as_float((unsigned)(u >> 32));
+                            } else {
 #pragma unroll
-                            for (int c = 0; c < CH; c++) X[m * CH + c] = xrow[((G::P * e + m) * p.S + g) * CH + c];
+                                for (int c = 0; c < CH; c++) X[m * CH + c] = xrow[((G::P * e + m) * p.S + g) * CH + c];
+                            }
+                        }
 #pragma unroll
                         for (int l = 0; l < 4; l++) Q[l] = X[l] * X[l];
                         {
@@ -439,7 +454,8 @@ int st_launch_td(nae_ctx* ctx, const StCfg& c, const StView& in, const TdRange& 
     const dim3 grid((unsigned)n_streams);
 #define NAE_TD(CHN, NCN) NAE_KLAUNCH(ctx, "st_td_kernel", (st_td_kernel<CHN, NCN>), grid, dim3(1024 / NCN), lds, ctx->stream, \
                                      dview(in, CHN), p, dout(out, CHN), mid_state, offs_dbg, offs_stride)
-    if (c.ch == 2) { if (nc == 4) NAE_TD(2, 4); else if (nc == 2) NAE_TD(2, 2); else NAE_TD(2, 1); }
+    if (c.ch == 2 && nc == 4 && p.S == 180) NAE_KLAUNCH(ctx, "st_td_kernel", (st_td_kernel<2, 4, 180>), grid, dim3(256), lds, ctx->stream, dview(in, 2), p, dout(out, 2), mid_state, offs_dbg, offs_stride);
+    else if (c.ch == 2) { if (nc == 4) NAE_TD(2, 4); else if (nc == 2) NAE_TD(2, 2); else NAE_TD(2, 1); }
     else { if (nc == 4) NAE_TD(1, 4); else if (nc == 2) NAE_TD(1, 2); else NAE_TD(1, 1); }
 #undef NAE_TD
     return nae_check(ctx, hipGetLastError(), "st_td_kernel");
