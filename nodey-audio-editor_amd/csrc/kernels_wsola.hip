@@ -80,13 +80,17 @@ struct TdParams {
 // Unit u lives at row u mod R, column u div R with R = NC * P; rows R .. R+P-2 repeat rows 0 .. P-2 one column on, so
 // that a group that wraps around the rows is still read at a fixed row offset.
 //   NC = 4: 256 threads, one window read feeds 4 candidates (throughput shape: several streams per CU)
+//   (round 5 measured two shapes that waste fewer of the 1024 candidate slots on C5's 912-candidate seek window — 5 candidates on 192 threads and 3 on
+//   320 threads, 960 slots each — at 10.6-10.9 and 13.5 ms against 9.6 ms for NC = 4: three waves per SIMD hide less, three candidates per window
+//   read load the LDS more; profiles/r05_wsola_sq.md.  Not kept.)
 //   NC = 2: 512 threads, 8 waves per stream (latency shape: at most ~2 streams per CU, down to a lone stream)
+constexpr int td_threads(int nc) { return 1024 / nc; }
 template <int CH, int NC> struct TdGeo {
     static constexpr int P = 4 / CH;
     static constexpr int R = NC * P;
     static constexpr int ROWS = R + P - 1;
     static constexpr int LANES = 64 / P;          // lanes that share one p
-    static constexpr int THREADS = 1024 / NC;
+    static constexpr int THREADS = td_threads(NC);
     static constexpr int WAVES = THREADS / 64;
     static constexpr int PF = (1344 + THREADS - 1) / THREADS;   // window frames one thread stages (seek + overlap <= 1344)
     static constexpr int CP = 4;                  // frames one thread has in flight while copying the body
@@ -107,7 +111,7 @@ __device__ unsigned g_td_arrivals[8 * 4 * 16];
 // address register instead of eight registers that are each advanced per trip: 7 of a trip's 229 vector instructions (round 5; instantiated for the
 // stereo 48-kHz geometry — overlap 384 frames — that BASELINE.json's configs run).
 template <int CH, int NC, int KS = 0>
-__global__ __launch_bounds__(1024 / NC, 4) void st_td_kernel(DView in, TdParams p_in, DOut out, float* __restrict__ mid_state,
+__global__ __launch_bounds__(td_threads(NC), 4) void st_td_kernel(DView in, TdParams p_in, DOut out, float* __restrict__ mid_state,
                                                          int32_t* __restrict__ offs_dbg, long long offs_stride)
 {
     TdParams p = p_in;
@@ -282,7 +286,7 @@ __global__ __launch_bounds__(1024 / NC, 4) void st_td_kernel(DView in, TdParams 
                         for (int q = 0; q < NC; q++) {
                             const int j = Gs - q;
                             if (!decltype(guarded)::value || (j >= 0 && j < ng)) {
-                                const int me = (e - q) & (NC - 1);
+                                const int me = ((e - q) % NC + NC) % NC;
 #pragma unroll
                                 for (int l = 0; l < 4; l++) {
                                     sc[q][l] = sc[q][l] + X[l] * M[me][l];
@@ -442,6 +446,8 @@ int st_launch_td(nae_ctx* ctx, const StCfg& c, const StView& in, const TdRange& 
     // workgroups per CU the search is latency-bound and 2 candidates per thread (twice the waves) is 1.2-1.6x faster;
     // 1 per thread loses everywhere (measured: tools/td_sweep.sh) and stays only as a test shape.
     int nc = n_streams >= 640 ? 4 : 2;
+    // five candidates per thread on three waves (960 slots) where that wastes fewer slots than four on up to four waves (256 per wave); stereo only
+    // (the mono window's bank layout is built for power-of-two row counts)
     if (ctx->dbg_td_nc == 1 || ctx->dbg_td_nc == 2 || ctx->dbg_td_nc == 4) nc = ctx->dbg_td_nc;
     TdParams p;
     p.ovl = c.ovl; p.seekl = c.seekl; p.body = c.body; p.first_skip = c.first_skip;
@@ -452,7 +458,7 @@ int st_launch_td(nae_ctx* ctx, const StCfg& c, const StView& in, const TdRange& 
     const size_t lds = ((size_t)(nc >= 4 ? 2 : 1) * rows * p.S * c.ch + (size_t)c.ovl * c.ch + 16 + 2 * (size_t)c.ovl) * sizeof(float);
     if (lds > 60 * 1024) return nae_fail(ctx, NAE_ERR_INVALID, "WSOLA window does not fit LDS");
     const dim3 grid((unsigned)n_streams);
-#define NAE_TD(CHN, NCN) NAE_KLAUNCH(ctx, "st_td_kernel", (st_td_kernel<CHN, NCN>), grid, dim3(1024 / NCN), lds, ctx->stream, \
+#define NAE_TD(CHN, NCN) NAE_KLAUNCH(ctx, "st_td_kernel", (st_td_kernel<CHN, NCN>), grid, dim3(td_threads(NCN)), lds, ctx->stream, \
                                      dview(in, CHN), p, dout(out, CHN), mid_state, offs_dbg, offs_stride)
     if (c.ch == 2 && nc == 4 && p.S == 180) NAE_KLAUNCH(ctx, "st_td_kernel", (st_td_kernel<2, 4, 180>), grid, dim3(256), lds, ctx->stream, dview(in, 2), p, dout(out, 2), mid_state, offs_dbg, offs_stride);
     else if (c.ch == 2) { if (nc == 4) NAE_TD(2, 4); else if (nc == 2) NAE_TD(2, 2); else NAE_TD(2, 1); }
