@@ -983,9 +983,123 @@ static void bench_host_path(int branches, double seconds, bool print)
 	std::cout << line << "\n";
 }
 
+// ---- where the host thread's ~10 us per source frame go: the per-frame operations timed by themselves, and the
+// benchmark graph grown node by node (each variant on `seconds` of 48 kHz stereo in 1152-sample frames, one runner thread)
+static double run_chain(int n_vol, bool mix, bool pitch, double seconds, size_t* switches)
+{
+	const int S = (int)(seconds * 48000);
+	Runner r;
+	int id = 1;
+	auto a = std::make_shared<Test_source>();
+	a->samples = uniform((size_t)S * 2, 500);
+	int prev = id++;
+	r.add_node(prev, a);
+	for (int k = 0; k < n_vol; k++)
+	{
+		auto g = std::make_shared<Audio_vol>();
+		g->set_volume(0.9f);
+		const int n = id++;
+		r.add_node(n, g);
+		r.add_link({prev, "output", n, "input"});
+		prev = n;
+	}
+	if (mix)
+	{
+		auto c = std::make_shared<Test_source>();
+		c->samples = uniform((size_t)S * 2, 501);
+		auto m = std::make_shared<Audio_amix>();
+		Json::Value v;
+		v["input_num"] = 2;
+		v["volumes0"] = 0.5; v["locks0"] = false;
+		v["volumes1"] = 0.5; v["locks1"] = false;
+		m->deserialize(v);
+		const int nc = id++, nm = id++;
+		r.add_node(nc, c); r.add_node(nm, m);
+		r.add_link({prev, "output", nm, "input_1"});
+		r.add_link({nc, "output", nm, "input_2"});
+		prev = nm;
+	}
+	if (pitch)
+	{
+		auto pm = std::make_shared<Pitch_modifier>();
+		Json::Value pv;
+		pv["pitch"] = 3.0;
+		pm->deserialize(pv);
+		const int n = id++;
+		r.add_node(n, pm);
+		r.add_link({prev, "output", n, "input"});
+		prev = n;
+	}
+	auto sink = std::make_shared<Test_sink>();
+	sink->lazy_consumer = false;
+	sink->keep = false;
+	const int ns = id++;
+	r.add_node(ns, sink);
+	r.add_link({prev, "output", ns, "input"});
+	const auto t0 = std::chrono::steady_clock::now();
+	const bool ok = r.run();
+	const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	CHECK(ok, "host-cost chain runs");
+	if (switches) *switches = r.context_switches();
+	return wall;
+}
+
+static void host_costs(double seconds)
+{
+	using clk = std::chrono::steady_clock;
+	auto ns_each = [](clk::time_point t0, size_t n) { return std::chrono::duration<double, std::nano>(clk::now() - t0).count() / n; };
+	const size_t N = 200000;
+	// (a) one output frame: shared Audio_frame + 32-byte aligned buffer for 1152 stereo f32 samples, and its release
+	auto t0 = clk::now();
+	for (size_t i = 0; i < N; i++)
+	{
+		auto f = std::make_shared<Audio_frame>();
+		Frame_data* d = f->data();
+		d->format = AV_SAMPLE_FMT_FLT; d->nb_samples = 1152; d->ch_layout.nb_channels = 2;
+		frame_get_buffer(d, 32);
+		reinterpret_cast<volatile float*>(d->data[0])[0] = 1.0f;
+	}
+	const double alloc_ns = ns_each(t0, N);
+	// (b) one 9216-byte copy (frame <-> page-locked staging), source and destination cycling through 16 MiB
+	std::vector<uint8_t> src(16 << 20), dst(16 << 20);
+	t0 = clk::now();
+	for (size_t i = 0; i < N; i++) std::memcpy(dst.data() + (i * 9216) % ((16 << 20) - 9216), src.data() + (i * 9216 * 7) % ((16 << 20) - 9216), 9216);
+	const double copy_ns = ns_each(t0, N);
+	// (c) one frame through a stream: try_push + try_pop
+	Audio_stream st;
+	auto fr = std::make_shared<Audio_frame>();
+	t0 = clk::now();
+	for (size_t i = 0; i < N; i++) { st.try_push(fr); (void)st.try_pop(); }
+	const double stream_ns = ns_each(t0, N);
+	// (d) the graph grown node by node; host us per source frame = wall / frames (the GPU work of these nodes is far shorter than the wall time)
+	const double frames = std::ceil(seconds * 48000 / 1152.0);
+	size_t sw[5] = {0, 0, 0, 0, 0};
+	run_chain(1, true, true, 2.0, nullptr);                      // untimed: contexts, first launches
+	const double w0 = run_chain(0, false, false, seconds, &sw[0]);
+	const double w1 = run_chain(1, false, false, seconds, &sw[1]);
+	const double w2 = run_chain(2, false, false, seconds, &sw[2]);
+	const double w3 = run_chain(1, true, false, seconds, &sw[3]);
+	const double w4 = run_chain(1, true, true, seconds, &sw[4]);
+	const double yield_ns = sw[0] ? w0 * 1e9 / sw[0] : 0.0;      // source -> sink only: almost nothing but stream operations and fiber switches
+	char line[1024];
+	std::snprintf(line, sizeof line,
+				  "HOST_COSTS {\"frame_alloc_ns\": %.0f, \"copy_9216B_ns\": %.0f, \"stream_push_pop_ns\": %.0f, \"source_to_sink_ns_per_fiber_switch\": %.0f, "
+				  "\"us_per_source_frame\": {\"source->sink\": %.2f, \"+volume\": %.2f, \"+volume+volume\": %.2f, \"+volume+amix(2)\": %.2f, "
+				  "\"+volume+amix(2)+pitch\": %.2f}, \"fiber_switches\": [%zu, %zu, %zu, %zu, %zu], \"frames_per_chain\": %.0f}",
+				  alloc_ns, copy_ns, stream_ns, yield_ns, w0 / frames * 1e6, w1 / frames * 1e6, w2 / frames * 1e6, w3 / frames * 1e6, w4 / frames * 1e6, sw[0], sw[1],
+				  sw[2], sw[3], sw[4], frames);
+	std::cout << line << "\n";
+}
+
 int main(int argc, char** argv)
 {
 	const std::string mode = argc > 1 ? argv[1] : "cpu";
+	if (mode == "hostcost")
+	{
+		host_costs(argc > 2 ? std::atof(argv[2]) : 120.0);
+		std::cout << (failures ? "SELFTEST FAILED " : "SELFTEST OK ") << mode << " failures=" << failures << "\n";
+		return failures ? 1 : 0;
+	}
 	if (mode == "bench")
 	{
 		const double seconds = argc > 2 ? std::atof(argv[2]) : 20.0;
