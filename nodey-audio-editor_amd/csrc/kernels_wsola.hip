@@ -543,9 +543,18 @@ __global__ __launch_bounds__(256, 8) void st_aa_kernel(DView in, AaParams p, DOu
     for (int kb = 0; kb < kAaLen; kb += 8) {
         float x[11][CH], h[8];
 #pragma unroll
-        for (int t = 0; t < 11; t++)
+        for (int t = 0; t < 11; t++) {
+            if (CH == 2) {
+                // one 8-byte read per stereo frame, kept from being paired: a ds_read2_b64 moves its 16 bytes per lane in twice the LDS time of two ds_read_b64
+                typedef __attribute__((address_space(3))) const volatile unsigned long long lds_u64;
+                const unsigned long long u = *(lds_u64*)(tile + ((t & 3) * kAaRow + tid + (kb >> 2) + (t >> 2)) * 2);
+                x[t][0] = __uint_as_float((unsigned)u);
+                x[t][CH - 1] = __uint_as_float((unsigned)(u >> 32));
+            } else {
 #pragma unroll
-            for (int c = 0; c < CH; c++) x[t][c] = tile[((t & 3) * kAaRow + tid + (kb >> 2) + (t >> 2)) * CH + c];
+                for (int c = 0; c < CH; c++) x[t][c] = tile[((t & 3) * kAaRow + tid + (kb >> 2) + (t >> 2)) * CH + c];
+            }
+        }
         {
             const float4 h0 = *reinterpret_cast<const float4*>(hs + kb), h1 = *reinterpret_cast<const float4*>(hs + kb + 4);
             h[0] = h0.x; h[1] = h0.y; h[2] = h0.z; h[3] = h0.w; h[4] = h1.x; h[5] = h1.y; h[6] = h1.z; h[7] = h1.w;
