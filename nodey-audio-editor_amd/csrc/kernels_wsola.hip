@@ -264,11 +264,12 @@ __global__ __launch_bounds__(td_threads(NC), 4) void st_td_kernel(DView in, TdPa
                         float X[4], Q[4];
 #pragma unroll
                         for (int m = 0; m < G::P; m++) {
-                            if (CH == 2 && KS != 0) {
-                                // one 8-byte read per stereo frame at an IMMEDIATE offset of the trip's one address register (ds_read_b64 takes 16 bits of
-                                // offset; the ds_read2_b32 the compiler picks for two floats of unknown alignment only 8 bits of dwords)
+                            if (CH == 2) {
+                                // one 8-byte read per stereo frame (the ds_read2_b32 the compiler picks for two floats of unknown alignment is banked per dword:
+                                // 32 lanes 8 bytes apart collide 2-way — 0.39 of the kernel's LDS cycles in round 4); with a compile-time stride it sits at an
+                                // IMMEDIATE offset of the trip's one address register (ds_read_b64 takes 16 bits of offset, ds_read2_b32 8 bits of dwords)
                                 typedef __attribute__((address_space(3))) const volatile unsigned long long lds_u64;   // volatile: two of them must not be paired into a ds_read2_b64 (twice the LDS time per byte)
-                                const unsigned long long u = *(lds_u64*)(xrow + ((G::P * e + m) * KS + g) * 2);
+                                const unsigned long long u = *(lds_u64*)(xrow + ((G::P * e + m) * (KS != 0 ? KS : p.S) + g) * 2);
                                 X[m * 2] = __uint_as_float((unsigned)u);
                                 X[m * 2 + 1] = __uint_as_float((unsigned)(u >> 32));
                             } else {
