@@ -99,8 +99,9 @@ constexpr size_t kLdsSpecStereo = kLdsTablesPad + kWaves * kPadScratchCf * sizeo
 // the first `coarse_streams` streams, then chunks of `chunk_f` (short: a quarter of the re-read at a chunk's head, but the launch's tail is
 // one SHORT chunk long) for the rest.  Which wave computes which chunk does not touch any result.
 // A wave's FIRST item is the one of its position in the grid (no atomic: 4096 waves drawing from one address at the same moment cost a
-// small batch 0.15 ms); item n_waves + counters[0]++ comes next.  counters[1]: waves that have finished — the last one zeroes both, so the
-// next launch on this context (same stream: launches are ordered) starts from zero without a memset.
+// small batch 0.15 ms); item n_waves + counter++ comes next.  The host zeroes the counter on the launch's stream in front of every launch
+// that draws (a 4-byte fill: ~3 us; an earlier form let the launch's last wave reset it — one launch that dies would have left every later
+// one on the context with a stale count).
 struct SpecWork {
     int chunk_c, chunk_f;
     unsigned cps_c, cps_f;         // chunks per stream, coarse / fine
@@ -318,14 +319,6 @@ __global__ __launch_bounds__(kThreads, 4) void spectrum_stereo_kernel(const floa
     if (!work.dynamic) break;
     item = work.n_waves + (unsigned)__builtin_amdgcn_readfirstlane((int)drawn);
     }   // next chunk
-    if (work.dynamic && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) {    // lane 0, recomputed: `lane` is not kept alive across the chunk loop
-        // this wave's last draw has returned (it is what ended the loop): once every wave of the launch has said so, nobody touches
-        // the counters any more and the last one resets them for the next launch
-        if (atomicAdd(&work.counters[1], 1u) + 1u == work.n_waves) {
-            atomicExch(&work.counters[0], 0u);
-            atomicExch(&work.counters[1], 0u);
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------------------ K7
@@ -941,6 +934,11 @@ int nae_launch_spectrum(nae_ctx* ctx, const nae_sig* src, size_t T, int ch, size
         if (groups > 2ll * ctx->n_cu) groups = 2ll * ctx->n_cu;
         w.n_waves = (unsigned)(groups * kWaves);
         w.dynamic = items > groups * kWaves ? 1u : 0u;
+        if (w.dynamic) {
+            (void)nae_use_device(ctx);
+            const hipError_t e = hipMemsetAsync(ctx->d_spec_ctr, 0, sizeof(unsigned), ctx->stream);
+            if (e != hipSuccess) return nae_check(ctx, e, "hipMemsetAsync(spectrum work counter)");
+        }
         const bool wide = (reinterpret_cast<uintptr_t>(dst) & 15) == 0 && dst_stream_stride % 2 == 0 && !ctx->dbg_spec_narrow;
         if (wide)
             NAE_KLAUNCH(ctx, "spectrum_stereo_kernel", spectrum_stereo_kernel<true>, dim3((unsigned)groups), dim3(kThreads),

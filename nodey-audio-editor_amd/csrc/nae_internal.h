@@ -20,7 +20,7 @@ struct nae_ctx {
     nae::cf* d_w512 = nullptr;   // exp(-2 pi i k/512),  k = 0..511
     nae::cf* d_t1024 = nullptr;  // exp(-2 pi i k/1024), k = 0..512
     float* d_hann = nullptr;     // periodic Hann, 1024
-    unsigned* d_spec_ctr = nullptr;  // work counters of the persistent stereo spectrum kernel (zero between launches; kernels_stft.hip)
+    unsigned* d_spec_ctr = nullptr;  // work counter of the persistent stereo spectrum kernel (zeroed on the stream in front of every drawing launch; kernels_stft.hip)
     // grow-only workspaces
     void* ws_phase = nullptr; size_t ws_phase_bytes = 0;
     void* ws_mid = nullptr;   size_t ws_mid_bytes = 0;
