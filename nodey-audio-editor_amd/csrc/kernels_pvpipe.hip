@@ -47,7 +47,10 @@ constexpr size_t kPipeLdsPerSlot = (2 * kPadScratchCf + kYCf) * sizeof(cf);
 // the windowed frames of the last kOlaGens steps (a block's oldest frame lies ceil(3 / kG) steps back)
 constexpr int pipe_ola_gens(int kG) { return kG >= 3 ? 2 : 3; }
 constexpr int kOlaQuarter = 256;                            // floats
-constexpr size_t pipe_lds_x_per_slot(int kG) { return kG == 1 ? 0 : 3 * kPhasePad * sizeof(uint32_t) + (size_t)pipe_ola_gens(kG) * 3 * kOlaQuarter * sizeof(float); }
+// kG = 1: 1 KiB per slot — the two channel waves of a stereo stream (adjacent slots) exchange their finished hop blocks there, so that each can write
+// one DENSE 1-KiB piece of the interleaved output (16 bytes per lane) instead of four dword stores that fill a quarter of every 16 bytes
+constexpr size_t kPipeXchgPerSlot = 1024;
+constexpr size_t pipe_lds_x_per_slot(int kG) { return kG == 1 ? kPipeXchgPerSlot : 3 * kPhasePad * sizeof(uint32_t) + (size_t)pipe_ola_gens(kG) * 3 * kOlaQuarter * sizeof(float); }
 constexpr size_t pipe_lds(int kG, int kS) { return kPipeLdsTables + kS * (kPipeLdsPerSlot + pipe_lds_x_per_slot(kG)); }
 static_assert(2 * pipe_lds(1, 4) <= 160 * 1024, "two workgroups per CU");
 static_assert(pipe_lds(2, 4) <= 160 * 1024 && pipe_lds(4, 4) <= 160 * 1024, "one workgroup per CU");
@@ -180,7 +183,9 @@ __global__ __launch_bounds__(pipe_threads(kS), kRich ? (kS == 4 ? 4 : 2) : 8) vo
     const int n = (int)(f_end - f_first);
     if (n <= 0) return;
     const int steps = (n + kG - 1) / kG;
-    const int T = steps + kDepth;
+    // interleaved stereo output, one frame per step: a finished block leaves one barrier later, through the exchange area (R3) — one more step for everybody
+    const bool dense_shape = kG == 1 && p.ch == 2 && out.fs == 2 && out.cs == 1;
+    const int T = steps + kDepth + (dense_shape ? 1 : 0);
     /*pipe:begin*/
     unsigned long long now = 0;                              // shader clock, read behind barrier B, used behind the next barrier A
     if (kG > 1 && role == 2) __builtin_amdgcn_s_setprio(1);   // frame-interleaved (one workgroup per CU): R2b one level up (1.10 against 1.15 ms at 128 streams)
@@ -469,6 +474,10 @@ __global__ __launch_bounds__(pipe_threads(kS), kRich ? (kS == 4 ? 4 : 2) : 8) vo
             for (int q = 0; q < 7; q++) { r_ta[q] = lds_ld(twa + lane + 64 * q); r_tb[q] = lds_ld(w64 + 8 * (lane & 7) + q + 1); }
         }
         bool had = false;                                     // kG > 1: a frame of this slot went through the previous step
+        // dense stores (kG = 1, interleaved stereo, 16-byte aligned stream): XB[channel][half][lane] = the lane's two sample pairs of the block
+        const bool dense = dense_shape && ((reinterpret_cast<uintptr_t>(optr - c) & 15) == 0);   // (optr - c: channel 0 of the stream)
+        int pend_be = -1;                                     // block waiting in the exchange area (wave-uniform; the same in both channel waves)
+        auto xchg = [&]() { return reinterpret_cast<cf*>(xbase + (size_t)(slot & ~1) * kPipeXchgPerSlot); };
         auto store_block = [&](long long be, const float (&o)[4]) {
             if (be >= b0 && be < b_end && be * NAE_HOP < p.mid_len) {
                 // buffer stores: scalar descriptor of the block + one 32-bit lane offset (plain pointer stores made hipcc
@@ -503,7 +512,34 @@ __global__ __launch_bounds__(pipe_threads(kS), kRich ? (kS == 4 ? 4 : 2) : 8) vo
             const bool active = iz >= 0 && iz < n && fz >= b0;
             pipe_barrier();                                   /*A*/  // the FFT input of frame fz is complete
             if (kG == 1) pipe_prio(prio_slot, role, now);
+            if (kG == 1 && pend_be >= 0) {
+                // both channels' blocks of the previous step are in XB: this wave writes half c of the interleaved block — samples 128 c + 2 lane, + 1 of
+                // both channels = 16 contiguous bytes per lane, 1 KiB per wave
+                const int lx = pipe_lane<!kRich>(lane);
+                const cf* XB = xchg();
+                const cf P0 = lds_ld(XB + (0 + c) * 64 + lx), P1 = lds_ld(XB + (2 + c) * 64 + lx);
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(optr - c + (long long)pend_be * (2 * NAE_HOP), 0, -1, 0x00020000);
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(P0.x), __float_as_uint(P1.x), __float_as_uint(P0.y), __float_as_uint(P1.y)}, rs,
+                                                       16 * lx, 1024 * c, 0);
+                pend_be = -1;
+            }
             cf zs[8];
+            // kG > 1: the three quarters that complete the previous step's block are requested in the SAME round trip as the FFT input (round 5: read
+            // behind pass A they cost the light barrier interval a second LDS round trip: R3 was the role it waited for, 1650 against R2a's 1400 cycles)
+            float4 oq[3];
+            const bool finish = kG > 1 && had && fz - kG - 3 >= b0;
+            if (finish) {
+                const int lq = pipe_lane<!kRich>(lane);
+#pragma unroll
+                for (int i = 3; i >= 1; i--) {
+                    const int rel = j - i;                                   // < 0: an earlier step
+                    const int back = rel >= 0 ? 0 : (-rel + kG - 1) / kG;
+                    const int sl = slot - j + rel + back * kG;
+                    const int gen = (t - 1 - back + 2 * kGens) % kGens;
+                    oq[i - 1] = *reinterpret_cast<const float4*>(x_ola(sl, gen) + (i - 1) * kOlaQuarter + 4 * lq);
+                }
+            }
             if (active) {
                 // FFT input and pass-A twiddles in one round trip; pass A is register-only, so it runs on this side of barrier B
                 const int la = pipe_lane<!kRich>(lane);
@@ -520,27 +556,15 @@ __global__ __launch_bounds__(pipe_threads(kS), kRich ? (kS == 4 ? 4 : 2) : 8) vo
                     fft512_pad_a_tw(zs, tw);
                 }
             }
-            if (kG > 1 && had) {
+            if (finish) {
                 // the block that the frame of the previous step completed: quarters 3, 2, 1 of the three frames before it
                 // (slot (j - i) mod kG, floor((j - i) / kG) steps earlier), then the own quarter 0 — the frame order
-                const long long be = fz - kG - 3;
-                if (be >= b0) {
-                    float o[4];
-                    const int lq = pipe_lane<!kRich>(lane);
+                float o[4] = {oq[2].x, oq[2].y, oq[2].z, oq[2].w};
+                o[0] += oq[1].x; o[1] += oq[1].y; o[2] += oq[1].z; o[3] += oq[1].w;
+                o[0] += oq[0].x; o[1] += oq[0].y; o[2] += oq[0].z; o[3] += oq[0].w;
 #pragma unroll
-                    for (int i = 3; i >= 1; i--) {
-                        const int rel = j - i;                                   // < 0: an earlier step
-                        const int back = rel >= 0 ? 0 : (-rel + kG - 1) / kG;
-                        const int sl = slot - j + rel + back * kG;
-                        const int gen = (t - 1 - back + 2 * kGens) % kGens;
-                        const float4 qv = *reinterpret_cast<const float4*>(x_ola(sl, gen) + (i - 1) * kOlaQuarter + 4 * lq);
-                        if (i == 3) { o[0] = qv.x; o[1] = qv.y; o[2] = qv.z; o[3] = qv.w; }
-                        else { o[0] += qv.x; o[1] += qv.y; o[2] += qv.z; o[3] += qv.w; }
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; i++) o[i] = (o[i] + y0[i]) * kGain;
-                    store_block(be, o);
-                }
+                for (int i = 0; i < 4; i++) o[i] = (o[i] + y0[i]) * kGain;
+                store_block(fz - kG - 3, o);
             }
             pipe_barrier();                                   /*B*/  // R2 may overwrite the FFT input
             if (kG == 1) now = __builtin_amdgcn_s_memtime();
@@ -572,7 +596,16 @@ __global__ __launch_bounds__(pipe_threads(kS), kRich ? (kS == 4 ? 4 : 2) : 8) vo
                         r1[i] = r2[i] + y[2][i];
                         r2[i] = y[3][i];
                     }
-                    store_block(fz - 3, o);                   // wave-uniform: the block's base pointer stays scalar
+                    const long long be = fz - 3;
+                    if (dense && be >= b0 && be < b_end && (be + 1) * NAE_HOP <= p.mid_len) {
+                        const int lx = pipe_lane<!kRich>(lane);
+                        cf* XB = xchg();
+                        lds_st(XB + (2 * c + 0) * 64 + lx, cf{o[0], o[1]});
+                        lds_st(XB + (2 * c + 1) * 64 + lx, cf{o[2], o[3]});
+                        pend_be = (int)be;
+                    } else {
+                        store_block(be, o);                   // wave-uniform: the block's base pointer stays scalar
+                    }
                 } else {
                     float* po = x_ola(slot, t % kGens) + 4 * lb;
 #pragma unroll
