@@ -49,6 +49,8 @@ constexpr int pipe_ola_gens(int kG) { return kG >= 3 ? 2 : 3; }
 constexpr int kOlaQuarter = 256;                            // floats
 // kG = 1: 1 KiB per slot — the two channel waves of a stereo stream (adjacent slots) exchange their finished hop blocks there, so that each can write
 // one DENSE 1-KiB piece of the interleaved output (16 bytes per lane) instead of four dword stores that fill a quarter of every 16 bytes
+// (Measured for the two-frames-per-step shape too — exchange behind barrier A, stores behind barrier B: 2.14-2.19 against 2.10-2.11 ms at 256 streams: in
+// that latency-bound regime the extra LDS round trip costs more than the denser stores give; four frames per step hold ONE channel per workgroup.)
 constexpr size_t kPipeXchgPerSlot = 1024;
 constexpr size_t pipe_lds_x_per_slot(int kG) { return kG == 1 ? kPipeXchgPerSlot : 3 * kPhasePad * sizeof(uint32_t) + (size_t)pipe_ola_gens(kG) * 3 * kOlaQuarter * sizeof(float); }
 constexpr size_t pipe_lds(int kG, int kS) { return kPipeLdsTables + kS * (kPipeLdsPerSlot + pipe_lds_x_per_slot(kG)); }
