@@ -323,6 +323,7 @@ def main():
         ctx.sync()
         w_ms = (time.perf_counter() - tw0) / 2 * 1e3
         ctx.prof_enable(False)
+        w_clock = ctx.clock_ghz()                            # probe kernel directly behind the WSOLA launches (not the vocoder step's clock)
         wk = {k: round(v[0] / max(v[1], 1), 4) for k, v in ctx.prof_report().items()}
         other = sum(v["avg_ms"] for k, v in kern_report.items() if not k.startswith(("pv_", "resample")))
         out["pitch_node_soundtouch_algorithm"] = {
@@ -342,15 +343,16 @@ def main():
                 continue
             scale = sf / td["sample_frames"]
             instr = td["valu_instr_per_launch"] * scale
-            cyc = avg_ms * 1e-3 * clock_ghz * 1e9
+            cyc = avg_ms * 1e-3 * w_clock * 1e9
             peak_cpi = valu_cycles_per_instr(td.get("waves_per_simd", 4))
             v_cyc, l_cyc = instr / 1024.0 * peak_cpi, td.get("lds_idx_active_per_cu", 0.0) * scale
             valu[kname] = {"wave_instr_per_launch": instr, "waves_per_simd": td.get("waves_per_simd", 4),
                            "achieved": round(cyc * 1024 / instr, 3), "peak": peak_cpi, "unit": "cycles per wave-instruction per SIMD (lower is better)",
                            "frac": round(peak_cpi * instr / 1024 / cyc, 3),
                            "valu_busy_cycles_per_simd": v_cyc, "lds_cycles_per_cu": l_cyc, "kernel_cycles": cyc,
-                           "floor_ms_at_this_clock": round(v_cyc / (clock_ghz * 1e9) * 1e3, 3)}
+                           "floor_ms_at_this_clock": round(v_cyc / (w_clock * 1e9) * 1e3, 3)}
         if valu:
+            out["pitch_node_soundtouch_algorithm"]["clock_GHz"] = round(w_clock, 3)
             out["pitch_node_soundtouch_algorithm"]["valu"] = valu
             out["pitch_node_soundtouch_algorithm"]["valu_source"] = wdata.get("_source")
         ctx.graph4(g)                                        # restore the vocoder result for the parity check below

@@ -11,7 +11,8 @@
 //   step t:   R1   frame t    load, Hann window, forward FFT                                         -> Z   (its own FFT scratch)
 //             R2a  frame t-1  bins lane+64r, r = 0..3: r2c split, atan2 -> Q0.32, phase advance, rotate -> Y   (hand-off buffer)
 //             R2b  frame t-1  the same for r = 4..7 and bin 512
-//             R3   frame t-2  c2r pre-twiddle, inverse FFT (by forward FFT), overlap-add, store the finished hop block
+//             R3   frame t-2  c2r pre-twiddle, inverse FFT (by forward FFT), overlap-add, store the finished hop block (interleaved stereo output:
+//                             one barrier later, as a dense 16-byte-per-lane piece assembled with the other channel's wave through LDS)
 //
 // (round 2 ran three roles at 80 VGPRs / 6 waves per SIMD: the phase role carried half of a frame's ~1100 vector
 // instructions and, issuing at the single-wave rate, set the step; profiles/r02_pipe_stamps*.txt.)
