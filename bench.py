@@ -222,6 +222,7 @@ def main():
         "pv_phase_kernel": 8.0 * sf,                     # re-read of the input (pass 1); output negligible
         "pv_scan_kernel": 0.0,
         "pv_pipe_kernel": 8.0 * sf + 8.0 * sf * mid_ratio,    # input once + stretched signal once
+        "pv_flow_kernel": 8.0 * sf + 8.0 * sf * mid_ratio,    # (the same node on at most one workgroup per CU: a rank's share of a multi-GPU job)
         "resample_kernel": 8.0 * sf * mid_ratio + 8.0 * sf,   # stretched signal once + output once
         "resample_tile_kernel": 8.0 * sf * mid_ratio + 8.0 * sf,
         "spectrum_stereo_kernel": 8.0 * sf + 2 * BINS * 4.0 * n_streams * F,   # 24.03 B per sample-frame

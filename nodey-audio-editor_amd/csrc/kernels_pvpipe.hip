@@ -37,17 +37,16 @@
 // atan2_q32 / phase increment as the other kernels); only where data waits between operations differs.
 // Replaces: SoundTouch behind /root/reference/src/processor/audio-velocity.cpp:369-428 (algorithm differs: DESIGN.md §3).
 #include "stft_common.h"
+#include "pv_roles.h"
 
 namespace nae {
 
 constexpr int pipe_threads(int kS) { return 64 * 4 * kS; }   // kS slots: waves [0,kS) = R1, [kS,2kS) = R2a, [2kS,3kS) = R2b, [3kS,4kS) = R3
-constexpr int kYCf = 520;                                   // Y[0..512] natural order
 constexpr size_t kPipeLdsTables = NAE_FFT_N * sizeof(float) + (kT1024Pad + 64 + kTwaCf) * sizeof(cf);
 constexpr size_t kPipeLdsPerSlot = (2 * kPadScratchCf + kYCf) * sizeof(cf);
 // frame-interleaved modes: per slot, analysis phases of the last two steps, one phase increment, and the quarters 1..3 of
 // the windowed frames of the last kOlaGens steps (a block's oldest frame lies ceil(3 / kG) steps back)
 constexpr int pipe_ola_gens(int kG) { return kG >= 3 ? 2 : 3; }
-constexpr int kOlaQuarter = 256;                            // floats
 // kG = 1: 1 KiB per slot — the two channel waves of a stereo stream (adjacent slots) exchange their finished hop blocks there, so that each can write
 // one DENSE 1-KiB piece of the interleaved output (16 bytes per lane) instead of four dword stores that fill a quarter of every 16 bytes
 // (Measured for the two-frames-per-step shape too — exchange behind barrier A, stores behind barrier B: 2.14-2.19 against 2.10-2.11 ms at 256 streams: in
@@ -57,10 +56,6 @@ constexpr size_t pipe_lds_x_per_slot(int kG) { return kG == 1 ? kPipeXchgPerSlot
 constexpr size_t pipe_lds(int kG, int kS) { return kPipeLdsTables + kS * (kPipeLdsPerSlot + pipe_lds_x_per_slot(kG)); }
 static_assert(2 * pipe_lds(1, 4) <= 160 * 1024, "two workgroups per CU");
 static_assert(pipe_lds(2, 4) <= 160 * 1024 && pipe_lds(4, 4) <= 160 * 1024, "one workgroup per CU");
-
-// every LDS operation of this wave has completed, then the workgroup barrier (vector-memory operations stay in flight:
-// the frame prefetch of R1 and the block stores of R3 must not be drained twice per step)
-__device__ __forceinline__ void pipe_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // Issue priority (kG = 1).  Two workgroups share a CU and the hardware arbitrates equal priorities by age, so the workgroup that
 // arrived first runs its steps 30-40 % faster than its neighbour on every CU, finishes early and leaves the CU half empty
@@ -86,35 +81,6 @@ __device__ __forceinline__ void pipe_prio(int slot, int role, unsigned long long
     else if (lvl == 1) __builtin_amdgcn_s_setprio(1);
     else if (lvl == 2) __builtin_amdgcn_s_setprio(2);
     else __builtin_amdgcn_s_setprio(3);
-}
-
-// the lane index as a value the optimiser cannot see through: addresses derived from it are recomputed where they are used
-// (one to four instructions each) instead of being hoisted out of the frame loop, where each would pin a VGPR of the 64.
-// Only where that matters: R1 and R3 of the 64-VGPR build; the phase roles have registers to spare (their hoisted addresses
-// stay below the kernel's maximum: -1.7 % kernel time), and the 128-VGPR builds hide nothing
-template <bool kHide = true>
-__device__ __forceinline__ int pipe_lane(int lane)
-{
-    if (kHide) asm volatile("" : "+v"(lane));
-    return lane;
-}
-
-// exact phase increment of one hop for bin k: adv + round(dw * R / 2^24)
-__device__ __forceinline__ uint32_t pipe_inc(uint32_t qa, uint32_t qp, unsigned k, unsigned d, unsigned R)
-{
-    const uint32_t e = ((k * d) & (NAE_FFT_N - 1)) << 22;
-    const int32_t dw = (int32_t)(qa - qp - e);
-    const uint32_t adv = ((k * NAE_HOP) & (NAE_FFT_N - 1)) << 22;
-    const long long scaled = ((long long)dw * (long long)(int32_t)R + (1ll << (NAE_R_FRAC_BITS - 1))) >> NAE_R_FRAC_BITS;
-    return adv + (uint32_t)scaled;
-}
-
-// synthesis bin X e^{i (qs - qa)} (tolerance path: v_sin / v_cos take turns)
-__device__ __forceinline__ cf pipe_rotate(cf x, uint32_t qs, uint32_t qa)
-{
-    const float ph = (float)(int32_t)(qs - qa) * (1.0f / 4294967296.0f);
-    const float cs = __builtin_amdgcn_cosf(ph), sn = __builtin_amdgcn_sinf(ph);
-    return cf{__builtin_fmaf(x.x, cs, -(x.y * sn)), __builtin_fmaf(x.x, sn, x.y * cs)};
 }
 
 template <bool kUnit, int kG, int kS, bool kRich>
@@ -660,6 +626,10 @@ int nae_launch_pv_pipe(nae_ctx* ctx, const PvParams& p, const SigViewD& src, lon
     // stereo units come in channel pairs of one (stream, tile): n_sc is even, so items is
     const long long groups = (items + units - 1) / units;
     if (groups > 0x7fffffffll) return nae_fail(ctx, NAE_ERR_INVALID, "pv_pipe_kernel: grid too large");
+    // at most one workgroup per CU, one frame per step (e.g. the 512 streams a rank of a 2-GPU job owns): the one-barrier pipeline with doubled
+    // hand-off buffers (kernels_pvflow.hip) is 5 % faster; in the frame-interleaved shapes it saves cycles and loses them to a lower clock
+    if (groups <= (long long)ctx->n_cu && !ctx->pv_lean && (ctx->pv_flow >= 2 || (ctx->pv_flow == 1 && frames_per_step == 1)))
+        return nae_launch_pv_flow(ctx, p, src, n_sc, phase_ws, out, unit_stride, frames_per_step);
     Tables tb{ctx->d_w512, ctx->d_t1024, ctx->d_hann};
     // kRich: at most one workgroup per CU anyway (the frame-interleaved modes by their LDS; four slots per workgroup on a grid
     // of at most n_cu workgroups) -> 128 VGPRs per wave, tables in registers

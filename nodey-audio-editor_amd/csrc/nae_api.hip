@@ -229,6 +229,7 @@ int nae_ctx_create(int device, nae_ctx** out)
     ctx->dbg_spec_generic = getenv("NAE_SPEC_GENERIC") != nullptr;
     ctx->dbg_spec_narrow = getenv("NAE_SPEC_NARROW") != nullptr;
     ctx->pv_lean = getenv("NAE_PV_LEAN") != nullptr;
+    if (const char* t = getenv("NAE_PV_FLOW")) ctx->pv_flow = atoi(t);
     if (const char* e = getenv("NAE_SPEC_CHUNK")) ctx->dbg_spec_chunk = atoi(e);
     if (const char* e = getenv("NAE_SPEC_FINE")) ctx->dbg_spec_fine = atoi(e);
     if (const char* e = getenv("NAE_SPEC_FINE_ROUNDS")) ctx->dbg_spec_fine_rounds = atoi(e);

@@ -528,19 +528,21 @@ def test_k7_pipeline_modes_agree_bit_for_bit(nae, ch, n_streams, L, rate, pitch)
     """The vocoder pipeline runs a stream-channel through its four roles one frame per step (large batches) or 2 / 4 consecutive
     frames per step (frame-interleaved: small batches), with or without time tiles (pass 1 + scan).  All shapes deliver the same
     samples bit for bit — same integer phases, same overlap-add order — and match the oracle within the tolerance.  The shapes are
-    forced through the tuning knobs NAE_PV_FPS / NAE_PV_TILE, read when a context is created."""
+    forced through the tuning knobs NAE_PV_FLOW / NAE_PV_FPS / NAE_PV_TILE, read when a context is created."""
     x = (0.5 * orc.fill_uniform(n_streams * L * ch, 77)).astype(np.float32)
     outs = {}
     try:
-        for fps in ("1", "2", "4"):
-            for tile in ("0", "64"):
-                os.environ["NAE_PV_FPS"], os.environ["NAE_PV_TILE"] = fps, tile
-                with nae.Context(0) as c:
-                    outs[(fps, tile)] = gpu_stretch(c, nae, x, ch, rate, pitch, n_streams=n_streams)[0]
+        for flow in ("0", "2"):          # two barriers per step (kernels_pvpipe.hip) / one barrier, doubled hand-off buffers (kernels_pvflow.hip)
+            for fps in ("1", "2", "4"):
+                for tile in ("0", "64"):
+                    os.environ["NAE_PV_FLOW"], os.environ["NAE_PV_FPS"], os.environ["NAE_PV_TILE"] = flow, fps, tile
+                    with nae.Context(0) as c:
+                        outs[(flow, fps, tile)] = gpu_stretch(c, nae, x, ch, rate, pitch, n_streams=n_streams)[0]
     finally:
+        os.environ.pop("NAE_PV_FLOW", None)
         os.environ.pop("NAE_PV_FPS", None)
         os.environ.pop("NAE_PV_TILE", None)
-    first = outs[("1", "0")]
+    first = outs[("0", "1", "0")]
     for key, o in outs.items():
         assert np.array_equal(o.view(np.uint32), first.view(np.uint32)), key
     per = first.reshape(n_streams, -1)

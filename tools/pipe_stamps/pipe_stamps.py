@@ -30,7 +30,7 @@ g.rate, g.pitch = 1.0, p
 g.pitch_out = nae.Sig.interleaved(d_pitch.ptr, pl.out_len, 2)
 g.spec_out, g.spec_stream_stride = d_spec.ptr, F * 2 * 513
 g.S, g.n_streams = S, n_streams
-for _ in range(3):
+for _ in range(int(os.environ.get("STAMP_ITERS", "3"))):     # STAMP_ITERS=400: the clock has settled where bench.py measures
     ctx.graph4(g)
 ctx.sync()
 st = np.zeros(16 * 8 * 4, np.uint64)

@@ -10,7 +10,7 @@ import json,sys
 d=json.loads(sys.stdin.read())
 k=d['kernels']
 g=lambda n: k.get(n,{}).get('avg_ms',0.0)
-pv=g('pv_pipe_kernel'); p1=g('pv_phase_kernel')+g('pv_scan_kernel')
+pv=g('pv_pipe_kernel')+g('pv_flow_kernel'); p1=g('pv_phase_kernel')+g('pv_scan_kernel')
 print('| %5d | %-4s | %7.3f | %6.3f | %6.3f | %6.3f | %6.3f | %.2f | %.3f |' % ($n, '$f', d['ms_per_step'], pv, p1, g('spectrum_stereo_kernel'), g('mix_resample_tile_kernel'), d['clock_GHz'], d['ms_per_step']*d['clock_GHz']))
 "
 done
