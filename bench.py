@@ -245,6 +245,10 @@ def main():
         avg_s = kernels[dom][0] / max(kernels[dom][1], 1) * 1e-3
         ach = alg_bytes.get(dom, 0.0) / avg_s / 1e9
         td = tdata.get(dom, {})
+        if dom == "pv_flow_kernel" and not td and "pv_pipe_kernel" in tdata:
+            # a rank's share of a multi-GPU job runs the one-barrier build of the same node: the same instructions, LDS traffic and bytes per frame
+            # (profiles/r05_flow.md), one workgroup per CU = 4 waves per SIMD; the counters were collected on the full batch's kernel
+            td = dict(tdata["pv_pipe_kernel"], waves_per_simd=4)
         scale = sf / td["sample_frames"] if td.get("sample_frames") else None
         traffic = td["hbm_bytes_per_launch"] * scale if scale and "hbm_bytes_per_launch" in td else None
         roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

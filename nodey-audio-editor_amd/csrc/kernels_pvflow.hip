@@ -41,10 +41,12 @@ constexpr size_t flow_lds_per_slot(int kG)
 }
 constexpr size_t flow_lds(int kG) { return kFlowSlots * flow_lds_per_slot(kG); }
 static_assert(flow_lds(1) <= 160 * 1024 && flow_lds(2) <= 160 * 1024 && flow_lds(4) <= 160 * 1024, "one workgroup per CU");
+// (A 64-VGPR build of the one-frame-per-step shape — tables in LDS, two workgroups per CU at exactly 80 KiB each, the priority time slices of
+// kernels_pvpipe.hip — was measured at 1024 streams: 6.39-6.44 against 6.10-6.18 ms; tools/experiments/r05_flow_lean.patch, profiles/r05_flow.md.)
 
 template <bool kUnit, int kG>
-__global__ __launch_bounds__(kFlowThreads) void pv_flow_kernel(SigViewD src, PvParams p, long long n_sc, const uint32_t* __restrict__ base_phase,
-                                                               OutViewD out, Tables tb)
+__global__ __launch_bounds__(kFlowThreads, 4) void pv_flow_kernel(SigViewD src, PvParams p, long long n_sc, const uint32_t* __restrict__ base_phase,
+                                                                  OutViewD out, Tables tb)
 {
     static_assert(kFlowSlots % kG == 0, "a unit's frames share a workgroup");
     constexpr int kUnits = kFlowSlots / kG;                  // stream-channels (x tile) per workgroup
@@ -92,7 +94,9 @@ __global__ __launch_bounds__(kFlowThreads) void pv_flow_kernel(SigViewD src, PvP
     if (n <= 0) return;
     const int steps = (n + kG - 1) / kG;
     constexpr int kR3Lag = kG == 1 ? 2 : 4;                            // steps between a frame's R1 step and its R3 step
-    const int T = steps + kR3Lag + (kG == 1 ? 0 : 1);                  // kG > 1: a block leaves one step behind its last frame
+    // interleaved stereo output, one frame per step: a finished block leaves one barrier later, as a dense piece assembled with the other channel's wave (R3)
+    const bool dense_shape = kG == 1 && p.ch == 2 && out.fs == 2 && out.cs == 1;
+    const int T = steps + kR3Lag + (kG == 1 ? (dense_shape ? 1 : 0) : 1);   // kG > 1: a block leaves one step behind its last frame
     /*pipe:begin*/
 
     if (role == 0) {
@@ -353,27 +357,37 @@ __global__ __launch_bounds__(kFlowThreads) void pv_flow_kernel(SigViewD src, PvP
 #pragma unroll
         for (int q = 0; q < 7; q++) { r_ta[q] = tb.w512[lane * (q + 1)]; r_tb[q] = tb.w512[8 * (lane & 7) * (q + 1)]; }
         bool had = false;                                     // kG > 1: a frame of this slot went through the previous step
+        // Dense stores (kG = 1, interleaved stereo, 16-byte aligned stream).  A wave holds its channel's finished block as samples 2 lane, + 1 (first half) and
+        // 128 + 2 lane, + 1 (second half); the wave of channel c stores HALF c of the interleaved block, 16 contiguous bytes per lane, 1 KiB per wave, instead of
+        // four dwords that fill half of every 8 bytes.  So it keeps its own half c in two registers and leaves the other half where its partner finds it one
+        // barrier later: entries 512..575 of the Y buffer it has just used up as FFT scratch.  Nobody else touches them: the transposes that reach up to entry
+        // 567 are this wave's own and are over by then, the phase waves fill entries 0..511 of that buffer in the next step (while the partner reads), and
+        // the buffer's next FFT — which overwrites them — is this wave's, two steps on.
+        const bool dense = dense_shape && ((reinterpret_cast<uintptr_t>(optr - c) & 15) == 0);   // (optr - c: channel 0 of the stream)
+        int pend_be = -1;                                     // block waiting for its other half (wave-uniform; the same in both channel waves)
+        float keep0 = 0.0f, keep1 = 0.0f;
         auto store_block = [&](long long be, const float (&o)[4]) {
             if (be >= b0 && be < b_end && be * NAE_HOP < p.mid_len) {
                 float* pb = optr + be * NAE_HOP * out.fs;
                 const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(pb, 0, -1, 0x00020000);
                 auto st = [&](unsigned byte_off, float v) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, (int)byte_off, 0, 0); };
+                const int ls = lane;
                 const unsigned fs4 = 4u * (unsigned)out.fs;                 // bytes between consecutive samples
-                const unsigned oa = 2u * (unsigned)lane * fs4;              // sample 2 lane of the block
+                const unsigned oa = 2u * (unsigned)ls * fs4;                // sample 2 lane of the block
                 if ((be + 1) * NAE_HOP <= p.mid_len) {
                     if (out_vec) {
                         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                        __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(o[0]), __float_as_uint(o[1])}, rs, (int)(8u * lane), 0, 0);
-                        __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(o[2]), __float_as_uint(o[3])}, rs, (int)(512u + 8u * lane), 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(o[0]), __float_as_uint(o[1])}, rs, (int)(8u * ls), 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(o[2]), __float_as_uint(o[3])}, rs, (int)(512u + 8u * ls), 0, 0);
                     } else {
                         st(oa, o[0]); st(oa + fs4, o[1]); st(oa + 128u * fs4, o[2]); st(oa + 129u * fs4, o[3]);
                     }
                 } else {
                     const int rem = (int)(p.mid_len - be * NAE_HOP);
-                    if (2 * lane + 0 < rem) st(oa, o[0]);
-                    if (2 * lane + 1 < rem) st(oa + fs4, o[1]);
-                    if (128 + 2 * lane < rem) st(oa + 128u * fs4, o[2]);
-                    if (129 + 2 * lane < rem) st(oa + 129u * fs4, o[3]);
+                    if (2 * ls + 0 < rem) st(oa, o[0]);
+                    if (2 * ls + 1 < rem) st(oa + fs4, o[1]);
+                    if (128 + 2 * ls < rem) st(oa + 128u * fs4, o[2]);
+                    if (129 + 2 * ls < rem) st(oa + 129u * fs4, o[3]);
                 }
             }
         };
@@ -385,6 +399,8 @@ __global__ __launch_bounds__(kFlowThreads) void pv_flow_kernel(SigViewD src, PvP
             pipe_barrier();                                   // the FFT input of frame fz is complete
             cf zs[8];
             cf* Yi = x_y(slot, (t & 1) ^ 1);
+            cf xh{0.0f, 0.0f};
+            if (kG == 1 && pend_be >= 0) xh = lds_ld(x_y(slot ^ 1, t & 1) + 512 + lane);   // the partner's half c of the previous step's block
             // kG > 1: the three quarters that complete the previous step's block, in the same round trip as the FFT input
             float4 oq[3];
             const bool finish = kG > 1 && had && fz - kG - 3 >= b0;
@@ -399,8 +415,17 @@ __global__ __launch_bounds__(kFlowThreads) void pv_flow_kernel(SigViewD src, PvP
                 }
             }
             if (active) {
+                const int la = lane;
 #pragma unroll
-                for (int r = 0; r < 8; r++) zs[r] = lds_ld(Yi + lane + 64 * r);
+                for (int r = 0; r < 8; r++) zs[r] = lds_ld(Yi + la + 64 * r);
+            }
+            if (kG == 1 && pend_be >= 0) {
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(optr - c + (long long)pend_be * (2 * NAE_HOP), 0, -1, 0x00020000);
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 v = c == 0 ? u32x4{__float_as_uint(keep0), __float_as_uint(xh.x), __float_as_uint(keep1), __float_as_uint(xh.y)}
+                                       : u32x4{__float_as_uint(xh.x), __float_as_uint(keep0), __float_as_uint(xh.y), __float_as_uint(keep1)};
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs, 16 * lane, 1024 * c, 0);
+                pend_be = -1;
             }
             if (finish) {
                 // quarters 3, 2, 1 of the three frames before it, then the own quarter 0 — the frame order
@@ -435,7 +460,15 @@ __global__ __launch_bounds__(kFlowThreads) void pv_flow_kernel(SigViewD src, PvP
                         r1[i] = r2[i] + y[2][i];
                         r2[i] = y[3][i];
                     }
-                    store_block(fz - 3, o);                   // wave-uniform: the block's base pointer stays scalar
+                    const long long be = fz - 3;
+                    if (dense && be >= b0 && be < b_end && (be + 1) * NAE_HOP <= p.mid_len) {
+                        lds_st(Yi + 512 + lane, c == 0 ? cf{o[2], o[3]} : cf{o[0], o[1]});   // the half the partner stores
+                        keep0 = c == 0 ? o[0] : o[2];
+                        keep1 = c == 0 ? o[1] : o[3];
+                        pend_be = (int)be;
+                    } else {
+                        store_block(be, o);                   // wave-uniform: the block's base pointer stays scalar
+                    }
                 } else {
                     float* po = x_ola(slot, t % (kGens > 0 ? kGens : 1)) + 4 * lane;
 #pragma unroll
@@ -485,6 +518,7 @@ int nae_launch_pv_flow(nae_ctx* ctx, const PvParams& p, const SigViewD& src, lon
     if (groups > 0x7fffffffll) return nae_fail(ctx, NAE_ERR_INVALID, "pv_flow_kernel: grid too large");
     Tables tb{ctx->d_w512, ctx->d_t1024, ctx->d_hann};
     int rc;
+    if (groups > (long long)ctx->n_cu) return nae_fail(ctx, NAE_ERR_INVALID, "pv_flow_kernel: more than one workgroup per CU");
     if (frames_per_step == 1) rc = flow_launch<1>(ctx, (unsigned)groups, src, p, n_sc, phase_ws, out, tb, unit_stride);
     else if (frames_per_step == 2) rc = flow_launch<2>(ctx, (unsigned)groups, src, p, n_sc, phase_ws, out, tb, unit_stride);
     else rc = flow_launch<4>(ctx, (unsigned)groups, src, p, n_sc, phase_ws, out, tb, unit_stride);

@@ -71,17 +71,7 @@ static_assert(pipe_lds(2, 4) <= 160 * 1024 && pipe_lds(4, 4) <= 160 * 1024, "one
 // Measured and dropped: keeping the pair level by feedback (each workgroup publishing its step counter, whoever is behind at the
 // higher priority: both then run at the pace of the slower, 7.8 against 7.3 ms); two-slot (eight-wave) workgroups, four per CU
 // (within 1 %).
-constexpr int kPrioSliceBit = 18;
 __device__ unsigned g_cu_arrivals[8 * 4 * 16];
-__device__ __forceinline__ void pipe_prio(int slot, int role, unsigned long long now)
-{
-    const int turn = (int)((now >> kPrioSliceBit) & 1);
-    const int lvl = (((turn + slot) & 1) ? 2 : 0) + (role == 3 ? 1 : 0);                // wave-uniform
-    if (lvl == 0) __builtin_amdgcn_s_setprio(0);
-    else if (lvl == 1) __builtin_amdgcn_s_setprio(1);
-    else if (lvl == 2) __builtin_amdgcn_s_setprio(2);
-    else __builtin_amdgcn_s_setprio(3);
-}
 
 template <bool kUnit, int kG, int kS, bool kRich>
 __global__ __launch_bounds__(pipe_threads(kS), kRich ? (kS == 4 ? 4 : 2) : 8) void pv_pipe_kernel(SigViewD src, PvParams p, long long n_sc,

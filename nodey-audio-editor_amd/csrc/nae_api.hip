@@ -147,7 +147,8 @@ int nae_ensure_rs_table(nae_ctx* ctx, double rate_eff)
 // Shape of the phase vocoder for a block call: frames per step of the pipeline (kernels_pvpipe.hip), synthesis tile, pass-1 tile.
 //   * more than 3 stream-channels per CU (>= 1024 at 256 CUs, e.g. 512 stereo streams): four stream-channels per workgroup
 //     (frames_per_step 1), ONE tile per stream-channel — no pass 1, nothing analysed twice; from 2048 stream-channels two
-//     workgroups share a CU.  (2 to 3 per CU: the frame-interleaved shape below in three rounds, see the code.)
+//     workgroups share a CU; up to 1024 stream-channels (one workgroup per CU) the launch runs the one-barrier build, kernels_pvflow.hip.
+//     (2 to 3 per CU: the frame-interleaved shape below in three rounds, see the code.)
 //   * fewer: the four slots of a workgroup work on 2 or 4 consecutive frames of one stream-channel (frame-interleaved), so
 //     256 stream-channels (the 128 streams one rank of an 8-GPU job owns) still give every CU a workgroup without cutting
 //     a stream into time tiles.  A workgroup of these modes fills a CU's LDS alone: 4 frames per step up to n_cu

@@ -42,4 +42,26 @@ __device__ __forceinline__ cf pipe_rotate(cf x, uint32_t qs, uint32_t qa)
     return cf{__builtin_fmaf(x.x, cs, -(x.y * sn)), __builtin_fmaf(x.x, sn, x.y * cs)};
 }
 
+// issue priority of a wave when two workgroups share a CU (kernels_pvpipe.hip, "Issue priority"): the workgroups take turns at the higher level in
+// time slices of 2^18 shader cycles, R3 sits one level above its workgroup's
+constexpr int kPrioSliceBit = 18;
+__device__ __forceinline__ void pipe_prio(int slot, int role, unsigned long long now)
+{
+    const int turn = (int)((now >> kPrioSliceBit) & 1);
+    const int lvl = (((turn + slot) & 1) ? 2 : 0) + (role == 3 ? 1 : 0);                // wave-uniform
+    if (lvl == 0) __builtin_amdgcn_s_setprio(0);
+    else if (lvl == 1) __builtin_amdgcn_s_setprio(1);
+    else if (lvl == 2) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(3);
+}
+
+// which of the two workgroups of its CU this one is (0 / 1, by arrival; thread 0 of the workgroup calls it): the parity of a counter per physical CU
+__device__ __forceinline__ int pipe_cu_arrival(unsigned* arrivals)
+{
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);            // HW_ID: CU 8-11, SE 13-14
+    const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 7u;     // XCC_ID
+    const unsigned key = (xcc * 4 + ((hw >> 13) & 3u)) * 16 + ((hw >> 8) & 15u);
+    return (int)(atomicAdd(&arrivals[key], 1u) & 1u);
+}
+
 } // namespace nae
