@@ -1,7 +1,7 @@
 """GPU, BASELINE.json's configs at their full sizes on one GPU.
 
-C5 (configs[4]): 1024 streams x 10 s through input -> mix(2) -> pitch -> spectrum, and the 128 streams one rank of the
-8-GPU job owns.  The oracle cannot run 1024 streams in seconds, so the whole batch is pinned through a size-independent
+C5 (configs[4]): 1024 streams x 10 s through input -> mix(2) -> pitch -> spectrum, and the 128 / 512 streams one rank of the
+8-GPU / 2-GPU job owns.  The oracle cannot run 1024 streams in seconds, so the whole batch is pinned through a size-independent
 property — streams share no state, hence EVERY stream of the batch must equal the same stream run ALONE, bit for bit
 (compared on the device) — and a few streams are compared with the oracle directly (the bars of the small tests: mix
 and spectrum-of-its-input bit-exact, pitch within 1e-4 relative RMS).
@@ -23,17 +23,17 @@ def slice_of(ctx, d, offset, count, dtype=np.float32):
     return out
 
 
-def run_graph(ctx, nae, d_a, d_b, n_streams, S, p, first_stream=0, want_wsola=False):
+def run_graph(ctx, nae, d_a, d_b, n_streams, S, p, first_stream=0, want_wsola=False, pitch_pad=0):
     pl = ctx.stretch_plan(1.0, p, S)
     F = ctx.spectrum_frames(pl.out_len)
-    d_mix, d_pitch, d_spec = ctx.empty(n_streams * S * 2), ctx.empty(n_streams * pl.out_len * 2), ctx.empty(n_streams * F * 2 * 513)
+    d_mix, d_pitch, d_spec = ctx.empty(n_streams * S * 2), ctx.empty(n_streams * pl.out_len * 2 + pitch_pad), ctx.empty(n_streams * F * 2 * 513)
     g = nae.Graph4()
     g.in_a = nae.Sig.interleaved(d_a.at(first_stream * S * 2), S, 2)
     g.in_b = nae.Sig.interleaved(d_b.ptr, S, 2, shared=True)
     g.vol_a = g.vol_b = 0.5
     g.mix_out = nae.Sig.planar(d_mix.ptr, S, 2)
     g.rate, g.pitch = 1.0, p
-    g.pitch_out = nae.Sig.interleaved(d_pitch.ptr, pl.out_len, 2)
+    g.pitch_out = nae.Sig.interleaved(d_pitch.at(pitch_pad), pl.out_len, 2)
     g.spec_out, g.spec_stream_stride = d_spec.ptr, F * 2 * 513
     g.S, g.n_streams = S, n_streams
     ctx.graph4(g)
@@ -116,6 +116,48 @@ def test_c5_eighth_of_the_job_128_streams(ctx, nae):
         assert np.array_equal(spec.view(np.uint32), orc.spectrum(pitch, 2).reshape(-1).view(np.uint32))
         assert rel_rms(spec, orc.spectrum(ref_p, 2).reshape(-1)) <= 1e-4
     for d in (d_a, d_b, d_mix, d_pitch, d_spec, d_cnt):
+        d.free()
+
+
+def test_c5_half_of_the_job_512_streams(ctx, nae):
+    """What one rank of a 2-GPU job owns (512 streams = 1024 stream-channels = one workgroup per CU, one frame per step): the vocoder then runs
+    its one-barrier pipeline (kernels_pvflow.hip: doubled hand-off buffers, dense block stores through the used-up buffer's tail).  On 2 s per
+    stream: all four outputs equal, bit for bit, those of a context that keeps the two-barrier pipeline (NAE_PV_FLOW=0); the same with the pitch
+    output 8 bytes off its 16-byte alignment (both kernels then fall back to dword stores); two streams against the oracle."""
+    import os
+    n_streams, S, p, first = 512, 96000, 2 ** (3 / 12), 512              # rank 1 of 2 owns streams 512..1023
+    d_a, d_b = ctx.empty(n_streams * S * 2), ctx.empty(S * 2)
+    ctx.fill_uniform(d_a.ptr, S * 2, S * 2, n_streams, first, 0)
+    ctx.fill_uniform(d_b.ptr, S * 2, 0, 1, 0, 1)
+    ctx.prof_reset(); ctx.prof_enable(True)
+    d_mix, d_pitch, d_spec, _, pl, F = run_graph(ctx, nae, d_a, d_b, n_streams, S, p)
+    ctx.sync(); ctx.prof_enable(False)
+    assert "pv_flow_kernel" in ctx.prof_report(), sorted(ctx.prof_report())
+    _, d_pitch_off, d_spec_off, _, _, _ = run_graph(ctx, nae, d_a, d_b, n_streams, S, p, pitch_pad=2)
+    d_cnt = ctx.empty(5, np.uint64).zero()
+    ctx.diff_words(d_pitch.ptr, d_pitch_off.at(2), n_streams * pl.out_len * 2, d_cnt.at(3))
+    ctx.diff_words(d_spec.ptr, d_spec_off.ptr, n_streams * F * 2 * 513, d_cnt.at(4))
+    os.environ["NAE_PV_FLOW"] = "0"
+    try:
+        with nae.Context(0) as c2:
+            ctx.sync()
+            c2.prof_reset(); c2.prof_enable(True)
+            m2, p2, s2, _, _, _ = run_graph(c2, nae, d_a, d_b, n_streams, S, p)
+            c2.sync(); c2.prof_enable(False)
+            assert "pv_pipe_kernel" in c2.prof_report() and "pv_flow_kernel" not in c2.prof_report()
+            ctx.diff_words(d_mix.ptr, m2.ptr, n_streams * S * 2, d_cnt.at(0))
+            ctx.diff_words(d_pitch.ptr, p2.ptr, n_streams * pl.out_len * 2, d_cnt.at(1))
+            ctx.diff_words(d_spec.ptr, s2.ptr, n_streams * F * 2 * 513, d_cnt.at(2))
+            assert d_cnt.download().tolist() == [0, 0, 0, 0, 0]
+    finally:
+        os.environ.pop("NAE_PV_FLOW", None)
+    b = orc.fill_uniform(S * 2, orc.stream_seed(0, 1))
+    for s in (0, 511):
+        pitch = slice_of(ctx, d_pitch, s * pl.out_len * 2, pl.out_len * 2)
+        a = orc.fill_uniform(S * 2, orc.stream_seed(first + s, 0))
+        L, R = orc.amix([a[0::2], b[0::2]], [a[1::2], b[1::2]], [0.5, 0.5])
+        assert rel_rms(pitch, orc.stretch(np.stack([L, R], 1).reshape(-1), 2, 1.0, p)) <= 1e-4
+    for d in (d_a, d_b, d_mix, d_pitch, d_spec, d_pitch_off, d_spec_off, d_cnt):
         d.free()
 
 
