@@ -170,6 +170,20 @@ int nae_pick_pv_shape(nae_ctx* ctx, size_t frames, size_t n_sc, int* phase_tile,
     if (ctx->pv_tile > 0) { *phase_tile = ctx->pv_tile; return ctx->pv_tile; }
     *phase_tile = 64;
     if (frames == 0 || n_sc == 0) return 64;
+    // Few LONG stream-channels (fewer than CUs, so time tiles and pass 1 are paid anyway): cut them into as many tiles as the FULL-batch shape wants —
+    // one frame per step, 8 n_cu (stream-channel, tile) items = two workgroups per CU at eight waves per SIMD, 1.37x the frames per second of the
+    // frame-interleaved shape — when a tile keeps >= 128 frames (its 4 priming / tail frames then cost <= 3 %).  One hour of stereo (BASELINE configs[2]):
+    // 1023 tiles of 660 frames per channel.  Pass 1 runs on half tiles (>= 4092 waves).  Never more than 8 n_cu items: one workgroup beyond two per CU
+    // would run alone in a second round.
+    if (ctx->pv_fps == 0 && n_sc < n_cu) {
+        const size_t want = 8 * n_cu / n_sc;                          // tiles per stream-channel, rounded down
+        if (want >= 2 && frames >= 128 * want) {
+            const size_t half = ((frames + want - 1) / want + 1) / 2;     // pass-1 tile: half a synthesis tile, >= 64 frames
+            *frames_per_step = 1;
+            *phase_tile = (int)half;
+            return (int)(2 * half);
+        }
+    }
     const size_t max_tiles = (frames + 63) / 64;
     // workgroups wanted: one per CU (two from 2048 stream-channels, where no tiles are needed anyway)
     const size_t wg = (n_sc * (size_t)fps + 3) / 4;                      // workgroups of one tile per stream-channel
