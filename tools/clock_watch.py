@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Sample the GPU's core clock and power (rocm-smi) while the C5 graph runs in a loop: is the step clock- or power-limited?
-   python tools/clock_watch.py [seconds]"""
+   python tools/clock_watch.py [seconds [streams [stage mask: 7 = whole graph, 2 = the vocoder alone]]]
+   (NAE_PV_FLOW=0|2 in the environment: two-barrier / one-barrier vocoder pipeline; profiles/r05_flow.md)"""
 import json
 import os
 import subprocess
@@ -14,7 +15,8 @@ import naeload
 
 nae = naeload.load()
 ctx = nae.Context(0)
-n, S, p = 1024, 480000, 2 ** (3 / 12)
+n, S, p = (int(sys.argv[2]) if len(sys.argv) > 2 else 1024), 480000, 2 ** (3 / 12)
+mask = int(sys.argv[3]) if len(sys.argv) > 3 else 7
 pl = ctx.stretch_plan(1.0, p, S)
 F = ctx.spectrum_frames(pl.out_len)
 d_a, d_b = ctx.empty(n * S * 2), ctx.empty(S * 2)
@@ -48,9 +50,28 @@ t = threading.Thread(target=watch); t.start()
 t0 = time.perf_counter(); steps = 0
 while time.perf_counter() - t0 < secs:
     for _ in range(10):
-        ctx.graph4(g)
+        if mask == 7:
+            ctx.graph4(g)
+        else:
+            ctx.graph4_stages(g, mask)
     ctx.sync(); steps += 10
 t1 = time.perf_counter(); stop = True; t.join()
 print("ms per step over %.1f s: %.3f" % (t1 - t0, (t1 - t0) / steps * 1e3))
 for ts, s in samples[:: max(1, len(samples) // 12)]:
     print("%.2f s" % (ts - t0), json.dumps(s)[:600])
+# averages over the second half of the run (settled)
+half = [s for ts, s in samples if ts - t0 > secs / 2 and isinstance(s, dict)]
+def num(v):
+    try:
+        return float(str(v).strip("()MhzW ").split()[0].replace("Mhz", ""))
+    except Exception:
+        return None
+acc = {}
+for s in half:
+    for card, d in s.items():
+        if isinstance(d, dict):
+            for k, v in d.items():
+                x = num(v)
+                if x is not None and ("sclk" in k.lower() or "power" in k.lower()):
+                    acc.setdefault(k, []).append(x)
+print("settled averages (%d samples):" % len(half), {k: round(sum(v) / len(v), 1) for k, v in acc.items()})
