@@ -322,23 +322,27 @@ __global__ __launch_bounds__(kThreads, 4) void spectrum_stereo_kernel(const floa
 }
 
 // ------------------------------------------------------------------------------------------------ K7
-// analysis of one frame: windowed load, FFT, split.  X[k] for k = kl+64r in v, X[512] returned.
-template <bool kUnit>
-__device__ __forceinline__ cf analyse(cf (&v)[8], const ChanView& in, long long s, const LdsLayout& L,
-                                      const FftTw& tw, int lane)
-{
-    load_frame_windowed<kUnit>(v, in, s, L.hann, lane);
-    fft512_fwd(v, L.scratch, tw, lane);
-    return rfft_split<true>(v, L.scratch, L.t1024, lane);   // 2 X: only phases are taken from it (pass 1)
-}
-
 // pass 1: per-tile sum of phase increments.  sums[(sc * n_tiles + tile) * 520 + k]
+// One wave per tile on the padded low-register FFT (stft_device.h; round 5 — rounds 1-4 ran the 100-VGPR swizzled FFT at four waves per SIMD): 80 VGPRs,
+// three 8-wave workgroups per CU = six waves per SIMD, which is what the LDS allows (12 KB of tables + 8 x 4.5 KB of scratch per workgroup).
+constexpr size_t kLdsPhase = kLdsTablesPad + kWaves * kPadScratchCf * sizeof(cf);
+static_assert(3 * kLdsPhase <= 160 * 1024, "three workgroups per CU");
 template <bool kUnit>
-__global__ __launch_bounds__(kThreads, 4) void pv_phase_kernel(SigViewD src, PvParams p, long long n_items,
+__global__ __launch_bounds__(kThreads, 6) void pv_phase_kernel(SigViewD src, PvParams p, long long n_items,
                                                               uint32_t* __restrict__ sums, Tables tb)
 {
-    LdsLayout L = lds_setup(tb);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* hann = reinterpret_cast<float*>(smem);
+    cf* t1024 = reinterpret_cast<cf*>(smem + NAE_FFT_N * sizeof(float));
+    cf* w64 = t1024 + kT1024Pad;
+    cf* twa = w64 + 64;
+    for (int i = threadIdx.x; i < NAE_FFT_N; i += kThreads) hann[i] = tb.hann[i];
+    for (int i = threadIdx.x; i < NAE_FFT_BINS; i += kThreads) t1024[i] = tb.t1024[i];
+    if (threadIdx.x < 64) w64[threadIdx.x] = tb.w512[8 * (threadIdx.x >> 3) * (threadIdx.x & 7)];
+    fill_twa(twa, tb.w512, threadIdx.x, kThreads);
+    __syncthreads();
     const int lane = threadIdx.x & 63;
+    cf* scratch = reinterpret_cast<cf*>(smem + kLdsTablesPad) + wave_id() * kPadScratchCf;
     const long long item = (long long)blockIdx.x * kWaves + wave_id();
     if (item >= n_items) return;
     const long long sc = item / p.n_tiles;
@@ -347,8 +351,6 @@ __global__ __launch_bounds__(kThreads, 4) void pv_phase_kernel(SigViewD src, PvP
     const long long s_idx = sc / p.ch;
     const int c = (int)(sc % p.ch);
     ChanView in{src.base + s_idx * src.ss + c * src.cs, src.fs, p.in_len};
-    FftTw tw;
-    load_fft_tw(tw, tb.w512, L.w64, lane);
     const int kl = kl_of_lane(lane);
 
     const long long f0 = p.f_origin + (long long)tile * p.tile;
@@ -364,7 +366,9 @@ __global__ __launch_bounds__(kThreads, 4) void pv_phase_kernel(SigViewD src, PvP
 #pragma unroll 1
     for (long long f = (f0 > 0 ? f0 - 1 : 0); f < f1; f++) {
         const long long s = frame_start(p, f);
-        const cf nyq = analyse<kUnit>(v, in, s, L, tw, lane);
+        load_frame_windowed<kUnit>(v, in, s, hann, lane);
+        fft512_pad(v, make_fft_lds(scratch, twa, w64, lane));
+        const cf nyq = rfft_split<true>(v, scratch, t1024, lane);   // 2 X: only phases are taken from it
         phases_of(v, nyq, qa);
         if (f < f0) {
             // priming frame: its increment belongs to the previous tile / call
@@ -415,6 +419,58 @@ __global__ void pv_scan_kernel(uint32_t* __restrict__ sums, long long n_sc, int 
         run += v;
     }
     if (carry_out) carry_out[sc * kT1024Pad + k] = run;
+}
+
+// the same for many tiles per stream-channel (a long lone stream: thousands of tiles on a few stream-channels, where one thread per bin walks them
+// one after the other): 16 threads per bin take a sixteenth of the tiles each — sum it, exchange the 16 sums through LDS, prefix the own part
+// (modular integer sums: the split changes no bit).  One workgroup per (stream-channel, 64 bins).
+constexpr int kScanChunks = 16;
+__global__ __launch_bounds__(64 * kScanChunks) void pv_scan_chunked_kernel(uint32_t* __restrict__ sums, long long n_sc, int n_tiles,
+                                                                          const uint32_t* __restrict__ carry_in, uint32_t* __restrict__ carry_out, int n_read)
+{
+    __shared__ uint32_t part[kScanChunks][64];
+    const int kb = threadIdx.x & 63, ck = threadIdx.x >> 6;
+    const long long sc = blockIdx.x / 9;
+    const int k = (int)(blockIdx.x % 9) * 64 + kb;
+    const bool valid = k < NAE_FFT_BINS;
+    const int per = (n_tiles + kScanChunks - 1) / kScanChunks;
+    const int j0 = ck * per, j1 = (j0 + per < n_tiles) ? j0 + per : n_tiles;
+    const int r1 = j1 < n_read ? j1 : n_read;                       // tiles at or beyond n_read count as zero
+    uint32_t* p = sums + sc * n_tiles * (long long)kT1024Pad + (valid ? k : 0);
+    uint32_t sum = 0;
+    if (valid) {
+        int j = j0;
+        for (; j + 8 <= r1; j += 8) {
+            uint32_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = p[(long long)(j + u) * kT1024Pad];
+#pragma unroll
+            for (int u = 0; u < 8; u++) sum += v[u];
+        }
+        for (; j < r1; j++) sum += p[(long long)j * kT1024Pad];
+    }
+    part[ck][kb] = sum;
+    __syncthreads();
+    uint32_t run = (valid && carry_in) ? carry_in[sc * kT1024Pad + k] : 0u;
+    for (int c2 = 0; c2 < ck; c2++) run += part[c2][kb];
+    if (!valid) return;
+    int j = j0;
+    for (; j + 8 <= r1; j += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = p[(long long)(j + u) * kT1024Pad];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            p[(long long)(j + u) * kT1024Pad] = run;
+            run += v[u];
+        }
+    }
+    for (; j < j1; j++) {
+        const uint32_t v = (j < n_read) ? p[(long long)j * kT1024Pad] : 0u;
+        p[(long long)j * kT1024Pad] = run;
+        run += v;
+    }
+    if (carry_out && ck == kScanChunks - 1) carry_out[sc * kT1024Pad + k] = run;
 }
 
 // rate transposer: out[j] = sum_i tab(phase)[i] * v[idx - 7 + i],  pos = j * step (Q32.32)
@@ -1026,7 +1082,7 @@ int nae_launch_pv_phase(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig*
         pp.skip_from = n_needed;
         const long long items = n_sc * p.n_tiles;
         const unsigned grid = (unsigned)((items + kWaves - 1) / kWaves);
-        const size_t lds = kLdsTables + kWaves * kLdsPerWaveSpec;
+        const size_t lds = kLdsPhase;
         if (src->frame_stride == 1)
             NAE_KLAUNCH(ctx, "pv_phase_kernel", (pv_phase_kernel<true>), dim3(grid), dim3(kThreads), lds, ctx->stream,
                         to_view(src), pp, items, phase_ws, tb);
@@ -1037,6 +1093,11 @@ int nae_launch_pv_phase(nae_ctx* ctx, const nae_stretch_plan* pl, const nae_sig*
         if (rc) return rc;
     }
     {
+        if (p.n_tiles >= 256 && n_sc * 9 <= 0x7fffffffll) {
+            NAE_KLAUNCH(ctx, "pv_scan_kernel", pv_scan_chunked_kernel, dim3((unsigned)(n_sc * 9)), dim3(64 * kScanChunks), 0, ctx->stream, phase_ws, n_sc, p.n_tiles,
+                        seg ? seg->carry_in : nullptr, seg ? seg->carry_out : nullptr, n_needed);
+            return nae_check(ctx, hipGetLastError(), "pv_scan_kernel");
+        }
         const long long threads = n_sc * kT1024Pad;
         const unsigned grid = (unsigned)((threads + 255) / 256);
         NAE_KLAUNCH(ctx, "pv_scan_kernel", pv_scan_kernel, dim3(grid), dim3(256), 0, ctx->stream, phase_ws, n_sc, p.n_tiles,

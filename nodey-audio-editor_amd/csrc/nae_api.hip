@@ -155,7 +155,7 @@ int nae_ensure_rs_table(nae_ctx* ctx, double rate_eff)
 //     stream-channels, 2 frames per step up to 2 n_cu.
 //   * fewer stream-channels than CUs: time tiles on top (each tile but the last of a stream-channel is analysed twice: pass 1
 //     sums its phase increments, pass 3 synthesises it), just enough of them for one workgroup per CU.  Pass 1 is one wave per
-//     tile and wants >= 4096 waves: it runs on tiles `step` times shorter (*phase_tile), never shorter than 64 frames; the
+//     tile and wants 24 n_cu waves (six per SIMD): it runs on tiles `step` times shorter (*phase_tile), never shorter than 64 frames; the
 //     synthesis tile is a multiple of it.
 int nae_pick_pv_shape(nae_ctx* ctx, size_t frames, size_t n_sc, int* phase_tile, int* frames_per_step)
 {
@@ -173,15 +173,16 @@ int nae_pick_pv_shape(nae_ctx* ctx, size_t frames, size_t n_sc, int* phase_tile,
     // Few LONG stream-channels (fewer than CUs, so time tiles and pass 1 are paid anyway): cut them into as many tiles as the FULL-batch shape wants —
     // one frame per step, 8 n_cu (stream-channel, tile) items = two workgroups per CU at eight waves per SIMD, 1.37x the frames per second of the
     // frame-interleaved shape — when a tile keeps >= 128 frames (its 4 priming / tail frames then cost <= 3 %).  One hour of stereo (BASELINE configs[2]):
-    // 1023 tiles of 660 frames per channel.  Pass 1 runs on half tiles (>= 4092 waves).  Never more than 8 n_cu items: one workgroup beyond two per CU
-    // would run alone in a second round.
+    // 1023 tiles of 660 frames per channel.  Pass 1 runs on thirds of a tile (6138 waves: six per SIMD).  Never more than 8 n_cu items: one workgroup
+    // beyond two per CU would run alone in a second round.
     if (ctx->pv_fps == 0 && n_sc < n_cu) {
         const size_t want = 8 * n_cu / n_sc;                          // tiles per stream-channel, rounded down
         if (want >= 2 && frames >= 128 * want) {
-            const size_t half = ((frames + want - 1) / want + 1) / 2;     // pass-1 tile: half a synthesis tile, >= 64 frames
+            size_t third = ((frames + want - 1) / want + 2) / 3;          // pass-1 tile: a third of a synthesis tile (6 n_cu x 4 waves), >= 43 frames
+            if (third < 64) third = 64;
             *frames_per_step = 1;
-            *phase_tile = (int)half;
-            return (int)(2 * half);
+            *phase_tile = (int)third;
+            return (int)(3 * third);
         }
     }
     const size_t max_tiles = (frames + 63) / 64;
@@ -189,7 +190,7 @@ int nae_pick_pv_shape(nae_ctx* ctx, size_t frames, size_t n_sc, int* phase_tile,
     const size_t wg = (n_sc * (size_t)fps + 3) / 4;                      // workgroups of one tile per stream-channel
     size_t n_synth = wg >= n_cu ? 1 : n_cu / wg;
     if (n_synth > max_tiles) n_synth = max_tiles;
-    size_t n_phase = n_synth == 1 ? 1 : (4096 + n_sc - 1) / n_sc;      // a single synthesis tile needs no pass 1
+    size_t n_phase = n_synth == 1 ? 1 : (24 * n_cu + n_sc - 1) / n_sc;   // a single synthesis tile needs no pass 1; else six waves per SIMD
     if (n_phase > max_tiles) n_phase = max_tiles;
     size_t step = (n_phase + n_synth - 1) / n_synth;
     if (step < 1) step = 1;

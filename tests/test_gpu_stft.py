@@ -523,6 +523,31 @@ def test_k7_k8_odd_layouts_equal_clean_layouts(ctx, nae):
             d_src.free(); d_dst.free(); d_o.free()
 
 
+def test_k7_many_tiles_equal_one_tile_bit_for_bit(nae):
+    """A long lone stream is cut into hundreds of time tiles: pass 1 sums each tile's phase increments (one wave per tile), pass 2 scans them — with
+    256 tiles or more per stream-channel by 16 threads per bin (pv_scan_chunked_kernel) — and pass 3 synthesises every tile from its carried phase.
+    92 s of stereo in 269 tiles of 64 frames, and in the library's own choice, equal the same stream run as ONE tile (no pass 1, no scan) bit for bit."""
+    ch, L, rate, pitch = 2, 4_400_000, 1.0, 2 ** (3 / 12)
+    x = (0.5 * orc.fill_uniform(L * ch, 99)).astype(np.float32)
+    outs = {}
+    try:
+        for key, env in (("one tile", {"NAE_PV_FPS": "1", "NAE_PV_TILE": "1000000"}), ("269 tiles", {"NAE_PV_TILE": "64"}), ("library", {})):
+            for k in ("NAE_PV_FPS", "NAE_PV_TILE"):
+                os.environ.pop(k, None)
+            os.environ.update(env)
+            with nae.Context(0) as c:
+                c.prof_reset(); c.prof_enable(True)
+                outs[key] = gpu_stretch(c, nae, x, ch, rate, pitch)[0]
+                c.prof_enable(False)
+                launched = set(c.prof_report())
+            assert ("pv_scan_kernel" in launched) == (key != "one tile"), (key, launched)
+    finally:
+        os.environ.pop("NAE_PV_FPS", None)
+        os.environ.pop("NAE_PV_TILE", None)
+    for key in ("269 tiles", "library"):
+        assert np.array_equal(outs[key].view(np.uint32), outs["one tile"].view(np.uint32)), key
+
+
 @pytest.mark.parametrize("ch,n_streams,L,rate,pitch", [(2, 3, 30000, 1.0, 2 ** (3 / 12)), (1, 5, 21001, 1.0, 2 ** (-4 / 12)), (2, 2, 9000, 1.5, 1 / 1.5)])
 def test_k7_pipeline_modes_agree_bit_for_bit(nae, ch, n_streams, L, rate, pitch):
     """The vocoder pipeline runs a stream-channel through its four roles one frame per step (large batches) or 2 / 4 consecutive
