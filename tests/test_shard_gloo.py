@@ -1,4 +1,4 @@
-"""CPU, world_size 2, gloo: the N>1 path of bench.py — strong-scaling stream sharding (a fixed job cut into contiguous
+"""CPU, world_size 2 and 4, gloo: the N>1 path of bench.py — strong-scaling stream sharding (a fixed job cut into contiguous
 slices, BASELINE.json configs[4]), the one-shot broadcast of the shared source buffer, and the max-over-ranks timing —
 exercised without a GPU."""
 import os
@@ -48,11 +48,12 @@ def _worker(rank, world, port, total, n, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_sharding_and_broadcast():
+@pytest.mark.parametrize("world,total", [(2, 5), (4, 10)])       # 5 streams over 2 ranks: slices of 2 and 3; 10 over 4: 2, 3, 2, 3
+def test_rank_sharding_and_broadcast(world, total):
     import torch.multiprocessing as mp
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orc
-    world, total, n = 2, 5, 4096                           # 5 streams over 2 ranks: slices of 2 and 3
+    n = 4096
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -72,15 +73,16 @@ def test_two_rank_sharding_and_broadcast():
     for rank, first, last, firsts, shared, elapsed, ranks in res:
         # every rank holds the same report: both ranks seen, their slices, their own step times and clocks, the broadcast's size
         assert ranks["ranks_seen"] == world and [d["rank"] for d in ranks["per_rank"]] == list(range(world))
-        assert [(d["first_stream"], d["last_stream"], d["streams"]) for d in ranks["per_rank"]] == [(0, 2, 2), (2, 5, 3)]
-        assert [d["ms_per_step"] for d in ranks["per_rank"]] == [10.0, 20.0]
-        assert [round(d["clock_GHz"], 6) for d in ranks["per_rank"]] == [2.0, 2.1]
+        cuts = [(r * total // world, (r + 1) * total // world) for r in range(world)]
+        assert [(d["first_stream"], d["last_stream"], d["streams"]) for d in ranks["per_rank"]] == [(a, b, b - a) for a, b in cuts]
+        assert [d["ms_per_step"] for d in ranks["per_rank"]] == [10.0 * (r + 1) for r in range(world)]
+        assert [round(d["clock_GHz"], 6) for d in ranks["per_rank"]] == [round(2.0 + 0.1 * r, 6) for r in range(world)]
         assert all(d["broadcast_bytes"] == 4 * n and d["broadcast_ms"] >= 0.0 for d in ranks["per_rank"])
         assert set(ranks["per_rank"][0]) == set(shard_fields)
         assert (first, last) == (rank * total // world, (rank + 1) * total // world)
         covered += list(range(first, last))
         assert np.array_equal(shared, ref_shared)               # broadcast delivered rank 0's buffer
-        assert abs(elapsed - 0.020) < 1e-9                      # max over ranks
+        assert abs(elapsed - 0.010 * world) < 1e-9              # max over ranks
         for i, s in enumerate(range(first, last)):
             assert firsts[i] == float(orc.fill_uniform(1, (0x9E3779B97F4A7C15 * (1 + s)) & 0xFFFFFFFFFFFFFFFF)[0])
     assert covered == list(range(total))                        # disjoint and complete
