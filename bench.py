@@ -270,9 +270,8 @@ def main():
                                 "achieved": round(ach_cpi, 3), "peak": peak_cpi, "unit": "cycles per wave-instruction per SIMD (lower is better)",
                                 "frac": round(peak_cpi / ach_cpi, 3),
                                 "peak_source": "profiles/r05_valu_wallclock.md (hipEvent wall clock + SQ_INSTS_VALU / GRBM_GUI_ACTIVE)",
-                                "note": "issue-slot account at the f32 add / mul / fma rate; compares, selects, conversions and integer multiplies (about a sixth of this "
-                                        "kernel's vector instructions) retire at 4.1 cycles on a second path that works BESIDE the first for other waves, "
-                                        "transcendentals at 8.1 (profiles/r05_valu_ops.md): frac is not the busy share of one unit",
+                                "note": "every instruction priced at the f32 add / mul / fma rate; by class (profiles/r05_valu_ops.md: compares, selects, conversions, "
+                                        "integer multiplies hold the arithmetic path ~1.6 cycles and their own port 4.1; transcendentals 8.1) this kernel reads the same",
                                 "valu_busy_cycles_per_simd": instr / 1024.0 * peak_cpi, "kernel_cycles": k_cyc,
                                 "lds": {"idx_active_cycles_per_cu": l_cyc, "frac_of_kernel": round(l_cyc / k_cyc, 3) if l_cyc else None,
                                         "note": "runs beside the vector ALU (valu + lds > kernel cycles: partial overlap, not a sum)"},
