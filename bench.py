@@ -11,12 +11,15 @@ Inputs are resident in HBM before the timed region.
     python bench.py                       # 1 GPU, defaults
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...          # no launcher around it: starts the line above as a CHILD process (before this process has
+                                          # touched HIP), relays rank 0's JSON line, exits non-zero with the child's stderr tail on failure
 
 Prints ONE JSON line on rank 0 (see README / DESIGN.md §4 for the fields).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -34,7 +37,7 @@ def valu_cycles_per_instr(waves_per_simd):
     return 4.6 if waves_per_simd <= 1 else 2.15
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -52,7 +55,85 @@ def parse():
     ap.add_argument("--no-alt", action="store_true", help="skip the side measurement of the SoundTouch-shaped pitch node")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-buffers-on-both-sides measurement (pcie_inclusive)")
     ap.add_argument("--no-host-path", action="store_true", help="skip the plugin-boundary measurement (host_path)")
-    return ap.parse_args()
+    ap.add_argument("--dry-run", action="store_true", help="rehearsal of the N > 1 plumbing on CPU (gloo): launcher, rendezvous, sharding, the broadcast, "
+                                                           "the rank reports and the one JSON line — no GPU work, `value` null (tests/test_shard_gloo.py)")
+    return ap.parse_args(argv)
+
+
+def usable_cores():
+    """CPUs this process may really use: its affinity mask, cut by a cgroup CPU quota if one is set (a quota leaves the mask at the host's count)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    cores = n if quota is None else max(1, min(n, int(quota + 0.5)))
+    return cores, {"host_cpus": os.cpu_count(), "affinity": n, "cgroup_cpu_quota": quota}
+
+
+def self_launch(a, argv):
+    """`python bench.py --gpus N` without a launcher around it (no WORLD_SIZE in the environment): start the documented
+    torch.distributed.run line as a CHILD process — this process has imported neither torch nor the HIP library, so nothing that has
+    initialised a GPU forks or execs — relay rank 0's single JSON line, and on failure exit non-zero with the tail of the child's stderr
+    (torch.distributed.run names the failing rank there).  One rank per GPU, as /root/reference/src/infra/runner.cpp:142-154 runs every
+    branch by itself."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL's only working mode on this pool's hosts
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or len(lines) != 1:
+        sys.stderr.write(f"bench.py --gpus {a.gpus}: the {a.gpus}-rank child job failed (exit code {r.returncode}, {len(lines)} result line(s)); "
+                         "the tail of its stderr:\n" + r.stderr[-4000:] + "\n")
+        sys.exit(r.returncode if r.returncode else 1)
+    if os.environ.get("NAE_BENCH_VERBOSE"):
+        sys.stderr.write(r.stderr[-4000:])
+    print(lines[0])
+    sys.stdout.flush()
+
+
+def dry_run_rank(a, rank, world):
+    """One rank of the CPU rehearsal (gloo): the same sharding, broadcast, rank reports and maximum over ranks as the GPU path, with a
+    small host buffer in place of the shared source and made-up step times (10 ms x (rank + 1)); rank 0 prints the JSON line."""
+    import torch
+    import naeload
+    naeload.load()
+    from nodey_audio_editor_amd import shard
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: launched as {world} rank(s) for --gpus {a.gpus}")
+    dist = shard.init("gloo", rank, world)
+    first, last = shard.strong_range(rank, world, a.total_streams) if a.streams is None else shard.stream_range(rank, a.streams)
+    t_b = torch.full((4096,), float(rank == 0), dtype=torch.float32)
+    bms, bbytes = shard.timed_broadcast_shared(dist, t_b, 0)
+    assert float(t_b[0]) == 1.0
+    ranks = shard.gather_rank_reports(dist, {"rank": rank, "first_stream": first, "last_stream": last, "streams": last - first,
+                                             "ms_per_step": 10.0 * (rank + 1), "clock_GHz": 0.0, "broadcast_ms": bms, "broadcast_bytes": bbytes})
+    elapsed = shard.max_over_ranks(dist, 0.010 * (rank + 1) * a.steps)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "stereo f32 sample-frames/s through the 4-node graph input->mix(2)->pitch->FFT-spectrum @48 kHz",
+                          "value": None, "dry_run": True, "unit": "sample-frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                          "ms_per_step": elapsed / a.steps * 1e3, "scaling": "weak" if a.streams is not None else "strong",
+                          "ranks": {"ranks_seen": ranks["ranks_seen"], "backend": "gloo (dry run)", "launched_world_size": world,
+                                    "per_rank": ranks["per_rank"], "streams_covered": sum(d["streams"] for d in ranks["per_rank"])}}))
+        sys.stdout.flush()
+    dist.destroy_process_group()
 
 
 def host_path(seconds=30.0):
@@ -80,10 +161,15 @@ def host_path(seconds=30.0):
 
 
 def main():
-    a = parse()
+    argv = sys.argv[1:]
+    a = parse(argv)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(a, argv)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.dry_run:
+        return dry_run_rank(a, rank, world)
     dist = None
     torch = None
     # stdout carries exactly ONE line, the JSON result: until that line is printed, file descriptor 1 points at stderr
@@ -96,11 +182,15 @@ def main():
         # torch first: its bundled libamdhip64.so.7 is then the one HIP runtime of the process (same soname as
         # /opt/rocm's, so libnae_gpu.so binds to it and device pointers are interchangeable)
         import torch
+        if world != a.gpus:
+            raise SystemExit(f"bench.py: launched as {world} rank(s) for --gpus {a.gpus}")
+        n_dev = torch.cuda.device_count()                    # (counting does not initialise a device)
+        if local_rank >= n_dev:
+            raise SystemExit(f"bench.py --gpus {a.gpus}: rank {rank} wants GPU {local_rank}, this box shows {n_dev} GPU(s)")
         torch.cuda.set_device(local_rank)
         nae = naeload.load()
         from nodey_audio_editor_amd import shard
         dist = shard.init("nccl", rank, world)               # "nccl" is RCCL on ROCm
-        assert world == a.gpus, f"launched {world} ranks for --gpus {a.gpus}"
 
     import numpy as np
     nae = naeload.load()
@@ -255,8 +345,8 @@ def main():
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "traffic_source": tdata.get("_source") if traffic is not None else None,
                     "avg_launch_ms": round(avg_s * 1e3, 4), "alg_bytes_per_launch": alg_bytes.get(dom, 0.0),
-                    "note": "K7 is bound by the vector ALU (two 512-point FFTs, atan2, sin/cos per bin: ~78 % busy at 2.15 cycles per wave64 "
-                            "instruction), with the LDS array busy beside it, not by HBM (valu block; DESIGN.md §4 and profiles/r05_valu_wallclock.md)"}
+                    "note": "K7 is bound by the vector ALU (two 512-point FFTs, atan2, sin/cos per bin: busy `valu.frac` of the kernel at 2.15 cycles "
+                            "per wave64 instruction), with the LDS array busy beside it, not by HBM (valu block; DESIGN.md §4 and profiles/r05_valu_wallclock.md)"}
         if scale and "valu_instr_per_launch" in td:
             # vector ALU: dynamic wave-instructions of the launch (SQ_INSTS_VALU) x 2.15 cycles per wave-instruction per SIMD (wall-clock
             # measured, profiles/r05_valu_wallclock.md) against the kernel's cycles at the clock measured in this run.  1024 SIMDs = 256 CUs x 4.
@@ -403,20 +493,20 @@ def main():
         # the same restatement on the box's CPU share, one stream per worker thread (a fair upper bound
         # for a CPU implementation; the reference itself runs every node on ONE thread).  ctypes drops the GIL in C.
         from concurrent.futures import ThreadPoolExecutor
-        workers = max(1, min(16, os.cpu_count() or 1))
+        workers, cpu_info = usable_cores()                 # every core this process may use; `cores` says how many
 
         def one(x):
             L, R = orc.amix([x[0::2], b[0::2]], [x[1::2], b[1::2]], [0.5, 0.5])
             orc.spectrum(orc.stretch(orc.interleave([L, R]), 2, a.rate, pitch), 2)
 
-        reps = max(1, (2 * workers + k - 1) // k)
+        reps = max(1, (4 * workers + k - 1) // k)           # at least four stream-runs per thread
         with ThreadPoolExecutor(workers) as ex:
-            list(ex.map(one, ins[:workers]))              # untimed: the first concurrent pass runs serially (arena set-up)
+            list(ex.map(one, (ins * reps)[:workers]))     # untimed: the first concurrent pass runs serially (arena set-up)
             tm0 = time.perf_counter()
             list(ex.map(one, ins * reps))
             tm1 = time.perf_counter()
         out["cpu_baseline"]["all_workers"] = {"value": k * reps * S / (tm1 - tm0), "unit": "sample-frames/s", "cores": workers,
-                                              "sample": f"{k * reps} stream-runs over {workers} threads", "seconds": round(tm1 - tm0, 2)}
+                                              "sample": f"{k * reps} stream-runs over {workers} threads, one stream per thread at a time", "seconds": round(tm1 - tm0, 2), **cpu_info}
         # parity of this very run: stream 0 of the GPU result against the oracle
         gp = np.empty(pl.out_len * 2, np.float32)
         gs = np.empty(F * 2 * BINS, np.float32)

@@ -28,6 +28,53 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Complex arithmetic on (re, im) register pairs.  The product is built with NAE_PK = 0: plain f32 instructions.
+// NAE_PK = 1 (a measured alternative, kept because it is bit-identical and small): hand-placed VOP3P instructions — one v_pk_add_f32 per
+// complex add / subtract (a multiplication by -i is an operand swap + one sign: op_sel / neg_lo / neg_hi, no instruction), one v_pk_mul_f32
+// + one v_pk_fma_f32 per twiddle product; no v_mov re-pairing (the compiler's own SLP packing needs those: Makefile).  Every component is
+// the SAME rounded operation as in the plain form (x - y == x + (-y), (-a) b == -(a b), fma(-a, b, c): sign changes of operands are
+// exact), and the two builds give the same bits on whole graphs (tools/lib_hash.py).  Round 6 measured it (profiles/r06_pk.md): the
+// static vector-instruction count of the vocoder falls 1428 -> 1206, a packed instruction holds the arithmetic path for 2.02x the cycles of
+// a plain one, and the kernels get SLOWER — vocoder 6.08 -> 6.21 ms, spectrum 2.75 -> 2.93 ms in the C5 step — at no better energy per
+// frame (the +10 % flops per joule of a v_pk_fma_f32 stream over a v_fma_f32 stream does not carry over to add-dominated butterflies).
+// NAE_PK = 2: only the twiddle products packed.
+#ifndef NAE_PK
+#define NAE_PK 0
+#endif
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f pk_v(cf a) { return v2f{a.x, a.y}; }
+__device__ __forceinline__ cf pk_c(v2f a) { return cf{a.x, a.y}; }
+#define NAE_PK2(name, text)                                                                            \
+    __device__ __forceinline__ cf name(cf a, cf b)                                                     \
+    {                                                                                                  \
+        v2f d;                                                                                         \
+        asm(text : "=v"(d) : "v"(pk_v(a)), "v"(pk_v(b)));                                              \
+        return pk_c(d);                                                                                \
+    }
+NAE_PK2(pk_add, "v_pk_add_f32 %0, %1, %2")                                                      // a + b
+NAE_PK2(pk_sub, "v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]")                            // a - b
+NAE_PK2(pk_add_mi, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]")         // a + (-i) b = (a.x + b.y, a.y - b.x)
+NAE_PK2(pk_sub_mi, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]")         // a - (-i) b = (a.x - b.y, a.y + b.x)
+NAE_PK2(pk_add_cj, "v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]")                                      // (a.x + b.x, a.y - b.y)
+NAE_PK2(pk_sub_cj, "v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]")                                      // (a.x - b.x, a.y + b.y)
+NAE_PK2(pk_swap_sub_add, "v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[0,1]")   // (a.y - b.x, a.x + b.y)
+NAE_PK2(pk_mul, "v_pk_mul_f32 %0, %1, %2")                                                      // (a.x b.x, a.y b.y)
+NAE_PK2(pk_mul_nh, "v_pk_mul_f32 %0, %1, %2 neg_hi:[1,0]")                                      // (a.x b.x, -(a.y b.y))
+NAE_PK2(pk_mul_xx, "v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]")                                   // (a.x b.x, a.x b.y)
+#undef NAE_PK2
+// (-a.y b.y + c.x, a.y b.x + c.y)
+__device__ __forceinline__ cf pk_fma_tw(cf a, cf b, cf c)
+{
+    v2f d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(d) : "v"(pk_v(a)), "v"(pk_v(b)), "v"(pk_v(c)));
+    return pk_c(d);
+}
+
+#if NAE_PK
+// v * w, one rounded product + one FMA per component
+__device__ __forceinline__ cf cmul_tw(cf v, cf w) { return pk_fma_tw(v, w, pk_mul_xx(v, w)); }
+#else
 __device__ __forceinline__ cf cmul_tw(cf v, cf w)
 {
     cf r;
@@ -35,6 +82,27 @@ __device__ __forceinline__ cf cmul_tw(cf v, cf w)
     r.y = __builtin_fmaf(v.y, w.x, v.x * w.y);
     return r;
 }
+#endif
+#if NAE_PK == 1
+__device__ __forceinline__ cf cadd(cf a, cf b) { return pk_add(a, b); }
+__device__ __forceinline__ cf csub(cf a, cf b) { return pk_sub(a, b); }
+
+// canonical forward 8-point DFT, in place, natural-order output: 28 packed instructions
+__device__ __forceinline__ void dft8_fwd(cf (&a)[8])
+{
+    const cf c{NAE_SQRT1_2, NAE_SQRT1_2};
+    const cf s0 = pk_add(a[0], a[4]), d0 = pk_sub(a[0], a[4]);
+    const cf s1 = pk_add(a[1], a[5]), e1 = pk_sub(a[1], a[5]);
+    const cf s2 = pk_add(a[2], a[6]), e2 = pk_sub(a[2], a[6]);
+    const cf s3 = pk_add(a[3], a[7]), e3 = pk_sub(a[3], a[7]);
+    const cf d1 = pk_mul(pk_add_mi(e1, e1), c);                   // ((e1.x + e1.y) c, (e1.y - e1.x) c)
+    const cf d3 = pk_mul_nh(pk_swap_sub_add(e3, e3), c);          // ((e3.y - e3.x) c, -((e3.x + e3.y) c))
+    const cf t0 = pk_add(s0, s2), t1 = pk_sub(s0, s2), t2 = pk_add(s1, s3), w3 = pk_sub(s1, s3);
+    const cf u0 = pk_add_mi(d0, e2), u1 = pk_sub_mi(d0, e2), u2 = pk_add(d1, d3), x3 = pk_sub(d1, d3);
+    a[0] = pk_add(t0, t2); a[4] = pk_sub(t0, t2); a[2] = pk_add_mi(t1, w3); a[6] = pk_sub_mi(t1, w3);
+    a[1] = pk_add(u0, u2); a[5] = pk_sub(u0, u2); a[3] = pk_add_mi(u1, x3); a[7] = pk_sub_mi(u1, x3);
+}
+#else
 __device__ __forceinline__ cf cadd(cf a, cf b) { return cf{a.x + b.x, a.y + b.y}; }
 __device__ __forceinline__ cf csub(cf a, cf b) { return cf{a.x - b.x, a.y - b.y}; }
 __device__ __forceinline__ cf mul_mi(cf a) { return cf{a.y, -a.x}; }
@@ -55,6 +123,7 @@ __device__ __forceinline__ void dft8_fwd(cf (&a)[8])
     a[0] = cadd(t0, t2); a[4] = csub(t0, t2); a[2] = cadd(t1, t3); a[6] = csub(t1, t3);
     a[1] = cadd(u0, u2); a[5] = csub(u0, u2); a[3] = cadd(u1, u3); a[7] = csub(u1, u3);
 }
+#endif
 
 // per-lane twiddles of the two twiddled passes, loop-invariant across frames
 struct FftTw {
@@ -333,15 +402,18 @@ __device__ __forceinline__ uint32_t atan2_q32(float im, float re)
     // (min of three with +inf: one v_min3_f32 — a two-operand fminf is preceded by two canonicalising v_max)
     const float mn = __builtin_fminf(__builtin_fminf(ax, ay), __builtin_inff());
     float r = __uint_as_float(NAE_RCP_MAGIC - __float_as_uint(mx));
+#ifndef NAE_ATAN_PROBE
+#define NAE_ATAN_PROBE 0      // 1: a TIMING probe of a revision 3 (two Newton steps, degree-5 polynomial: 3 instructions less; not the specification's values)
+#endif
 #pragma unroll
-    for (int it = 0; it < 3; it++) {
+    for (int it = 0; it < (NAE_ATAN_PROBE ? 2 : 3); it++) {
         const float e = __builtin_fmaf(-mx, r, 1.0f);
         r = __builtin_fmaf(r, e, r);
     }
     const float t = mn * r;
     const float s = t * t;
     float q = NAE_ATAN_C6 * NAE_ATAN_SCALE;
-    q = __builtin_fmaf(q, s, NAE_ATAN_C5 * NAE_ATAN_SCALE);
+    if (!NAE_ATAN_PROBE) q = __builtin_fmaf(q, s, NAE_ATAN_C5 * NAE_ATAN_SCALE);
     q = __builtin_fmaf(q, s, NAE_ATAN_C4 * NAE_ATAN_SCALE);
     q = __builtin_fmaf(q, s, NAE_ATAN_C3 * NAE_ATAN_SCALE);
     q = __builtin_fmaf(q, s, NAE_ATAN_C2 * NAE_ATAN_SCALE);

@@ -101,3 +101,33 @@ def test_job_throughput_is_whole_job(nae):
         sizes = [b - a for a, b in cuts]
         assert max(sizes) - min(sizes) <= 1
     assert shard.job_throughput_total(1024, 480000, 5, 0.25) == 1024 * 480000 * 5 / 0.25
+
+
+def test_bench_self_launch_dry_run_world_2():
+    """`python bench.py --gpus 2` with no launcher around it: the parent (which has touched neither torch nor HIP) starts
+    torch.distributed.run as a child, two gloo ranks rendezvous on 127.0.0.1, shard 5 streams 2 + 3, broadcast, gather their reports, and
+    the parent relays exactly ONE JSON line carrying the `ranks` block."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "3", "--total-streams", "5"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dry_run"] is True and d["value"] is None and d["scaling"] == "strong"
+    rk = d["ranks"]
+    assert rk["ranks_seen"] == 2 and rk["launched_world_size"] == 2 and rk["streams_covered"] == 5
+    assert [(p["rank"], p["first_stream"], p["last_stream"]) for p in rk["per_rank"]] == [(0, 0, 2), (1, 2, 5)]
+    assert d["ms_per_step"] == pytest.approx(20.0)            # the slowest rank's (made-up) 10 ms x (rank + 1)
+
+
+def test_bench_self_launch_reports_a_failing_child_plainly():
+    """a rank that cannot run (here: --gpus 2 on a box without GPUs, or a world / --gpus mismatch) ends the parent non-zero with that rank's
+    own message in the relayed stderr tail, and with no result line on stdout"""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode != 0 and "launched as 1 rank(s) for --gpus 2" in r.stderr and r.stdout.strip() == ""
