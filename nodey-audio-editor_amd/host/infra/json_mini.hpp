@@ -5,6 +5,7 @@
 #include <map>
 #include <string>
 #include <variant>
+#include <vector>
 
 namespace Json
 {
@@ -49,5 +50,12 @@ namespace Json
 			return 0.0;
 		}
 		size_t size() const { return members.size(); }
+		// JsonCpp: Value::Members = std::vector<std::string>, in key order
+		std::vector<std::string> getMemberNames() const
+		{
+			std::vector<std::string> names;
+			for (const auto& kv : members) names.push_back(kv.first);
+			return names;
+		}
 	};
 }

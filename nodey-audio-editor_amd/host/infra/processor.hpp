@@ -6,7 +6,9 @@
 //   Product (:32-39) · Pin_attribute (:42-49) · Info (:52-59) · Runtime_error (:64-77) · processor_map (:80)
 //   the pure virtuals (:86-113) · register_processor<T> (:116-129) · get_input_item / get_output_item (:134-176)
 // What differs is forced by this image's toolchain: Json::Value comes from json_mini.hpp, std::format from format.hpp.
-// The two GUI hooks (draw_title, draw_content) are empty here: drawing is the editor's business.
+// The two GUI hooks (draw_title, draw_content) are PURE virtual here as in the reference (:99-104): every GPU processor declares them, and
+// ../processor/draw-headless.cpp holds their bodies without a GUI — the one file an integrator replaces with the reference's own ImGui
+// bodies, which are the only code that changes a node's parameters while the editor runs.
 #pragma once
 
 #include <any>
@@ -82,8 +84,8 @@ namespace infra
 		virtual Info get_processor_info_non_static() const = 0;
 		virtual Json::Value serialize() const = 0;
 		virtual void deserialize(const Json::Value& value) = 0;
-		virtual void draw_title() {}
-		virtual bool draw_content(bool /*readonly*/) { return false; }
+		virtual void draw_title() = 0;
+		virtual bool draw_content(bool readonly) = 0;
 		virtual void process_payload(
 			const Input_map& input,
 			const Output_map& output,

@@ -15,6 +15,8 @@ namespace processor
 
 		static infra::Processor::Info get_processor_info();
 		Processor::Info get_processor_info_non_static() const override { return get_processor_info(); }
+		void draw_title() override;                         // bodies: draw-headless.cpp (the integrator keeps the reference's ImGui bodies instead)
+		bool draw_content(bool readonly) override;
 		std::vector<infra::Processor::Pin_attribute> get_pin_attributes() const override;
 		void process_payload(
 			const std::map<std::string, std::shared_ptr<infra::Processor::Product>>& input,

@@ -42,6 +42,8 @@ class Test_source : public infra::Processor
 	}
 	Json::Value serialize() const override { return {}; }
 	void deserialize(const Json::Value&) override {}
+	void draw_title() override {}
+	bool draw_content(bool) override { return false; }
 	void process_payload(const std::map<std::string, std::shared_ptr<Product>>&,
 						 const std::map<std::string, std::set<std::shared_ptr<Product>>>& output,
 						 const std::atomic<bool>& stop_token, std::any&) override
@@ -95,6 +97,8 @@ class Test_sink : public infra::Processor
 	}
 	Json::Value serialize() const override { return {}; }
 	void deserialize(const Json::Value&) override {}
+	void draw_title() override {}
+	bool draw_content(bool) override { return false; }
 	void process_payload(const std::map<std::string, std::shared_ptr<Product>>& input,
 						 const std::map<std::string, std::set<std::shared_ptr<Product>>>&, const std::atomic<bool>& stop_token,
 						 std::any&) override
@@ -285,6 +289,58 @@ static void test_registry_and_json()
 	vel->deserialize(q);
 	CHECK(vel->serialize()["velocity"].asFloat() == 1.5f && vel->serialize()["keep_pitch"].asBool(), "velocity JSON");
 	CHECK(infra::Processor::processor_map["audio_volume_adjust"].generate()->serialize().isNull(), "volume is not serialised (audio-vol.hpp:57-58)");
+}
+
+// what the mirror's registry holds, one line per processor, for tests/test_ref_pin.py to compare with the TEXT of the reference's sources:
+// identifier, display name, singleton flag, the pins of a default-constructed node (identifier, direction) and the keys its serialize() emits
+static void print_registry()
+{
+	infra::Processor::processor_map.clear();
+	infra::register_all_processors();
+	for (const auto& [id, info] : infra::Processor::processor_map)
+	{
+		auto node = info.generate();          // make_unique<T>: compiles only if T overrides every pure virtual of infra::Processor
+		node->draw_title();
+		(void)node->draw_content(true);
+		std::cout << "PROC {\"identifier\": \"" << info.identifier << "\", \"display_name\": \"" << info.display_name << "\", \"singleton\": "
+				  << (info.singleton ? "true" : "false") << ", \"same_info_non_static\": "
+				  << (node->get_processor_info_non_static().identifier == info.identifier ? "true" : "false") << ", \"pins\": [";
+		bool first = true;
+		for (const auto& pin : node->get_pin_attributes())
+		{
+			std::cout << (first ? "" : ", ") << "[\"" << pin.identifier << "\", " << (pin.is_input ? "true" : "false") << ", "
+					  << (pin.type.get() == typeid(Audio_stream) && pin.generate_func && dynamic_cast<Audio_stream*>(pin.generate_func().get()) ? "true" : "false") << "]";
+			first = false;
+		}
+		std::cout << "], \"json_keys\": [";
+		first = true;
+		const Json::Value v = node->serialize();
+		for (const auto& key : v.getMemberNames())
+		{
+			std::cout << (first ? "" : ", ") << "\"" << key << "\"";
+			first = false;
+		}
+		std::cout << "]}\n";
+	}
+}
+
+// the GUI hooks without a GUI (draw-headless.cpp): what the reference's bodies do to the parameters when no widget is touched
+static void test_headless_draw_hooks()
+{
+	Audio_vol vol;
+	vol.set_volume(3.0f);
+	CHECK(!vol.draw_content(false) && vol.get_volume() == 3.0f, "volume inside [0, 10] stays (audio-vol.cpp:266-274)");
+	Audio_amix amix;
+	Json::Value v;
+	v["input_num"] = 3;
+	const float w[3] = {0.5f, 0.25f, 0.75f};
+	for (int i = 0; i < 3; i++) { v[infra::fmt("volumes%d", i)] = w[i]; v[infra::fmt("locks%d", i)] = (i == 1); }
+	amix.deserialize(v);
+	CHECK(!amix.draw_content(false), "no pin change reported");
+	const Json::Value back = amix.serialize();
+	// audio-amix.cpp:379-387: the unlocked weights are divided by their sum (1.25), a locked one stays
+	CHECK(back["volumes0"].asFloat() == 0.5f / 1.25f && back["volumes1"].asFloat() == 0.25f && back["volumes2"].asFloat() == 0.75f / 1.25f,
+		  "mixer weights renormalised as the GUI does: " << back["volumes0"].asFloat() << " " << back["volumes1"].asFloat() << " " << back["volumes2"].asFloat());
 }
 
 static void test_error_capture()
@@ -1100,6 +1156,11 @@ int main(int argc, char** argv)
 		std::cout << (failures ? "SELFTEST FAILED " : "SELFTEST OK ") << mode << " failures=" << failures << "\n";
 		return failures ? 1 : 0;
 	}
+	if (mode == "registry")
+	{
+		print_registry();
+		return 0;
+	}
 	if (mode == "bench")
 	{
 		const double seconds = argc > 2 ? std::atof(argv[2]) : 20.0;
@@ -1111,6 +1172,7 @@ int main(int argc, char** argv)
 	}
 	test_streams_and_scheduler();
 	test_registry_and_json();
+	test_headless_draw_hooks();
 	test_bimix_align_step();
 	test_default_stretch_algorithm();
 	test_velocity_cadence_rules();
