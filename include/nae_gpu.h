@@ -30,8 +30,9 @@ extern "C" {
  * nae_wsola_*, nae_swr_* — and one CHANGED behaviour: nae_ctx_create of a second device used to return NAE_ERR_UNSUPPORTED behind a
  * process-wide latch; now a context may sit on any device, and an index outside [0, nae_device_count()) is NAE_ERR_INVALID.
  * A caller built against 1 keeps working (nothing was removed or re-typed); a caller that needs the additions checks
- * nae_abi_version() >= 2. */
-#define NAE_ABI_VERSION 2
+ * nae_abi_version() >= 2.
+ * 3 (round 6): addition — nae_debug_set (the tuning / A-B switches, formerly 14 environment variables read at context creation). */
+#define NAE_ABI_VERSION 3
 
 typedef enum nae_status {
     NAE_OK = 0,
@@ -114,6 +115,20 @@ int nae_prof_get(nae_ctx* ctx, int index, char* name, size_t name_cap, double* t
 /* shader clock (GHz) the GPU holds at this moment, from s_memtime / s_memrealtime stamps of a 1024-workgroup probe kernel
  * launched on the context's stream: lets a benchmark turn its own kernel times into cycles without assuming a clock. */
 int nae_debug_clock_ghz(nae_ctx* ctx, double* ghz);
+
+/* Tuning / A-B switches of one context (tests and measurement tools; the defaults are the product).  Takes effect from the next call on.
+ * Unknown key or value out of range: NAE_ERR_INVALID.  Keys (value 0 = the library's own choice unless said otherwise):
+ *   pv_tile         frames per phase-vocoder time tile (pass 1 and pass 3)
+ *   pv_fps          1 | 2 | 4: frames per step of the vocoder pipeline
+ *   pv_flow         0 | 1 | 2: launches of at most one workgroup per CU run the one-barrier schedule never / with one frame per step (default 1) / always
+ *   pv_lean         1: the pipeline keeps its 64-VGPR two-workgroups-per-CU build even when one workgroup per CU would allow 128
+ *   rs_single, rs_direct, no_mix_fuse      1: transposer with one stream per workgroup / the direct (unstaged) kernel / mix and transposer as two launches
+ *   spec_generic, spec_narrow              1: skip the interleaved-stereo spectrum kernel / its dword stores instead of 16-byte ones
+ *   spec_chunk, spec_fine, spec_fine_rounds   frames per chunk of the stereo spectrum kernel / of the short chunks at a launch's end / how many of those per wave
+ *   td_nc           1 | 2 | 4: candidates per thread of the WSOLA search;  st_unfused  1: filter and cubic stage of the WSOLA chain as two launches
+ * The same assignments, comma separated, in the environment variable NAE_DEBUG ("pv_flow=2,pv_fps=4") are applied when a context is created
+ * (for measuring a program that creates its contexts itself, e.g. bench.py); an unknown key there fails nae_ctx_create with NAE_ERR_INVALID. */
+int nae_debug_set(nae_ctx* ctx, const char* key, long long value);
 
 /* test utility: adds the number of differing 32-bit words of two device buffers to the device counter *d_count (zero it
  * first with nae_memset); asynchronous on the context's stream. */

@@ -20,7 +20,7 @@ EXPORTED_SYMBOLS = [
     "nae_memcpy_h2d", "nae_memcpy_d2h", "nae_memcpy_d2d", "nae_memset", "nae_event_create", "nae_event_record",
     "nae_event_query", "nae_ctx_wait_event", "nae_debug_graph4_stages",
     "nae_event_elapsed_ms", "nae_event_destroy", "nae_prof_enable", "nae_prof_reset", "nae_prof_get",
-    "nae_malloc_host", "nae_free_host", "nae_debug_clock_ghz", "nae_debug_diff_u32", "nae_fill_uniform_f32", "nae_gain_f32", "nae_gain_s16", "nae_gain_s32", "nae_gain_frame",
+    "nae_malloc_host", "nae_free_host", "nae_debug_clock_ghz", "nae_debug_set", "nae_debug_diff_u32", "nae_fill_uniform_f32", "nae_gain_f32", "nae_gain_s16", "nae_gain_s32", "nae_gain_frame",
     "nae_deinterleave_f32", "nae_interleave_f32", "nae_copy_sig_f32", "nae_gain_sig_f32", "nae_amix_f32",
     "nae_amix_sig_f32", "nae_bimix_f32", "nae_bimix2_downmix_f32", "nae_bimix2_interleave_f32",
     "nae_to_f32_interleaved", "nae_clamp_f32", "nae_stretch_plan_make", "nae_stretch_block_f32",
@@ -119,7 +119,7 @@ def load_library() -> C.CDLL:
         "nae_prof_enable": (i, [vp, i]), "nae_prof_reset": (i, [vp]),
         "nae_prof_get": (i, [vp, i, C.c_char_p, sz, P(d), P(C.c_uint64)]),
         "nae_malloc_host": (i, [vp, sz, P(vp)]), "nae_free_host": (i, [vp, vp]),
-        "nae_debug_clock_ghz": (i, [vp, P(C.c_double)]),
+        "nae_debug_clock_ghz": (i, [vp, P(C.c_double)]), "nae_debug_set": (i, [vp, C.c_char_p, C.c_longlong]),
         "nae_debug_diff_u32": (i, [vp, vp, vp, sz, vp]),
         "nae_fill_uniform_f32": (i, [vp, vp, sz, sz, sz, C.c_uint64, C.c_uint64]),
         "nae_gain_f32": (i, [vp, P(vp), P(vp), i, sz, f]), "nae_gain_s16": (i, [vp, P(vp), P(vp), i, sz, f]),
@@ -266,11 +266,22 @@ class Context:
     def __exit__(self, *a):
         self.close()
 
+    def debug_set(self, key: str, value: int) -> "Context":
+        """tuning / A-B switch of this context (include/nae_gpu.h lists the keys); returns self so that calls chain"""
+        self._ck(self.lib.nae_debug_set(self.h, key.encode(), int(value)))
+        return self
+
     # -- events
     def event(self) -> C.c_void_p:
         e = C.c_void_p()
         self._ck(self.lib.nae_event_create(self.h, C.byref(e)))
         return e
+
+    def destroy_event(self, ev) -> None:
+        """events are destroyed BEFORE the context they were created from (include/nae_gpu.h)"""
+        rc = self.lib.nae_event_destroy(ev)
+        if rc:
+            raise NaeError(f"nae_event_destroy failed: {rc}")
 
     def record(self, ev) -> None:
         self._ck(self.lib.nae_event_record(self.h, ev))

@@ -187,7 +187,7 @@ __global__ __launch_bounds__(kThreads, 4) void spectrum_stereo_kernel(const floa
             if (lane == 0) __builtin_amdgcn_raw_buffer_store_b64(u32x2{q[4].x, q[4].y}, rs, 0, 4096, kSpecStoreAux);
         }
     };
-    const u32x4* stq = reinterpret_cast<const u32x4*>(scratch) + lane;   // staged pieces [64 i]; [256] = floats 1024..1027 (lane 0)
+    const u32x4* stq = reinterpret_cast<const u32x4*>(scratch) + lane;   // staged pieces [64 i] per lane; floats 1024..1027 lie at piece 256 of the scratch (read with a lane-independent address)
     auto store_frame = [&](int fs) {
         // buffer stores: scalar descriptor of the frame's two spectra + one lane offset (no 64-bit per-lane addresses)
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(obase + ((long long)fs * 2) * NAE_FFT_BINS, 0, -1, 0x00020000);
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(kThreads, 4) void spectrum_stereo_kernel(const floa
         if (kWide && f > f0) {
 #pragma unroll
             for (int i = 0; i < 4; i++) q[i] = stq[64 * i];
-            q[4] = stq[256];
+            q[4] = reinterpret_cast<const u32x4*>(scratch)[256];   // every lane reads the SAME 16 bytes (inside the wave's scratch); lane 0's copy is stored
         }
         if (kWide && f > f0) {
             emit_frame(f - 1, q, f - 1 == f0, false);
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(kThreads, 4) void spectrum_stereo_kernel(const floa
             u32x4 q[5];
 #pragma unroll
             for (int i = 0; i < 4; i++) q[i] = stq[64 * i];
-            q[4] = stq[256];
+            q[4] = reinterpret_cast<const u32x4*>(scratch)[256];   // every lane reads the SAME 16 bytes (inside the wave's scratch); lane 0's copy is stored
             emit_frame(f1 - 1, q, f1 - 1 == f0, true);
             wave_lds_sync();
         }

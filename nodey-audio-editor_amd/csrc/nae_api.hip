@@ -2,6 +2,8 @@
 // No CPU compute path exists in this library: every transform is a HIP kernel launch; if HIP is unusable the
 // entry points fail with NAE_ERR_HIP.
 #include "nae_internal.h"
+#include <string>
+#include <initializer_list>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -170,12 +172,14 @@ int nae_pick_pv_shape(nae_ctx* ctx, size_t frames, size_t n_sc, int* phase_tile,
     if (ctx->pv_tile > 0) { *phase_tile = ctx->pv_tile; return ctx->pv_tile; }
     *phase_tile = 64;
     if (frames == 0 || n_sc == 0) return 64;
-    // Few LONG stream-channels (fewer than CUs, so time tiles and pass 1 are paid anyway): cut them into as many tiles as the FULL-batch shape wants —
-    // one frame per step, 8 n_cu (stream-channel, tile) items = two workgroups per CU at eight waves per SIMD, 1.37x the frames per second of the
-    // frame-interleaved shape — when a tile keeps >= 128 frames (its 4 priming / tail frames then cost <= 3 %).  One hour of stereo (BASELINE configs[2]):
-    // 1023 tiles of 660 frames per channel.  Pass 1 runs on thirds of a tile (6138 waves: six per SIMD).  Never more than 8 n_cu items: one workgroup
-    // beyond two per CU would run alone in a second round.
-    if (ctx->pv_fps == 0 && n_sc < n_cu) {
+    // Few LONG stream-channels — at most half as many as CUs, where the frame-interleaved shape below needs time tiles and pass 1 anyway: cut them into as
+    // many tiles as the FULL-batch shape wants — one frame per step, 8 n_cu (stream-channel, tile) items = two workgroups per CU at eight waves per SIMD, 1.37x
+    // the frames per second of the frame-interleaved shape — when a tile keeps >= 128 frames (its 4 priming / tail frames then cost <= 3 %).  One hour of stereo
+    // (BASELINE configs[2]): 1023 tiles of 660 frames per channel.  Pass 1 runs on thirds of a tile (6138 waves: six per SIMD).  Never more than 8 n_cu items:
+    // one workgroup beyond two per CU would run alone in a second round.  Between n_cu / 2 and n_cu stream-channels the frame-interleaved shape runs ONE tile
+    // per stream-channel (no pass 1) and wins: 96 / 112 / 127 streams of 10 s 1.53 / 1.64 / 1.75 ms per graph step against 1.55 / 1.74 / 2.00 with tiles;
+    // 40 and 80 streams tie (profiles/r06_shape_sweep.md).
+    if (ctx->pv_fps == 0 && 2 * n_sc <= n_cu) {
         const size_t want = 8 * n_cu / n_sc;                          // tiles per stream-channel, rounded down
         if (want >= 2 && frames >= 128 * want) {
             size_t third = ((frames + want - 1) / want + 2) / 3;          // pass-1 tile: a third of a synthesis tile (6 n_cu x 4 waves), >= 43 frames
@@ -217,6 +221,31 @@ int nae_device_count(void)
 // the context's device first when it differs (nae_use_device: one hipGetDevice on the fast path) and leaves it selected.
 // No process-global state: launch attributes are tracked per context, so contexts may be created and driven from different
 // threads as long as ONE thread at a time drives a given context and its handles (include/nae_gpu.h, "Threads").
+int nae_debug_set(nae_ctx* ctx, const char* key, long long value)
+{
+    if (!ctx || !key) return NAE_ERR_INVALID;
+    const std::string k(key);
+    const bool flag = value == 0 || value == 1;
+    const bool count = value >= 0 && value <= 0x7fffffffll;
+    auto one_of = [&](std::initializer_list<long long> ok) { for (long long v : ok) if (v == value) return true; return false; };
+    if (k == "pv_tile" && count) ctx->pv_tile = (int)value;
+    else if (k == "pv_fps" && one_of({0, 1, 2, 4})) ctx->pv_fps = (int)value;
+    else if (k == "pv_flow" && one_of({0, 1, 2})) ctx->pv_flow = (int)value;
+    else if (k == "pv_lean" && flag) ctx->pv_lean = value != 0;
+    else if (k == "rs_single" && flag) ctx->dbg_rs_single = value != 0;
+    else if (k == "rs_direct" && flag) ctx->dbg_rs_direct = value != 0;
+    else if (k == "no_mix_fuse" && flag) ctx->dbg_no_mix_fuse = value != 0;
+    else if (k == "spec_generic" && flag) ctx->dbg_spec_generic = value != 0;
+    else if (k == "spec_narrow" && flag) ctx->dbg_spec_narrow = value != 0;
+    else if (k == "spec_chunk" && count) ctx->dbg_spec_chunk = (int)value;
+    else if (k == "spec_fine" && count) ctx->dbg_spec_fine = (int)value;
+    else if (k == "spec_fine_rounds" && count) ctx->dbg_spec_fine_rounds = (int)value;
+    else if (k == "td_nc" && one_of({0, 1, 2, 4})) ctx->dbg_td_nc = (int)value;
+    else if (k == "st_unfused" && flag) ctx->dbg_st_unfused = value != 0;
+    else return nae_fail(ctx, NAE_ERR_INVALID, "nae_debug_set: unknown key or value out of range");
+    return NAE_OK;
+}
+
 int nae_ctx_create(int device, nae_ctx** out)
 {
     if (!out) return NAE_ERR_INVALID;
@@ -235,20 +264,24 @@ int nae_ctx_create(int device, nae_ctx** out)
     }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return NAE_ERR_HIP; }
     ctx->own_stream = true;
-    if (const char* t = getenv("NAE_PV_TILE")) ctx->pv_tile = atoi(t) > 0 ? atoi(t) : 0;   // tuning knob (0 = automatic)
-    if (const char* t = getenv("NAE_PV_FPS")) ctx->pv_fps = atoi(t);
-    ctx->dbg_rs_single = getenv("NAE_RS_SINGLE") != nullptr;
-    ctx->dbg_no_mix_fuse = getenv("NAE_NO_MIX_FUSE") != nullptr;
-    if (const char* e = getenv("NAE_TD_NC")) ctx->dbg_td_nc = atoi(e);
-    ctx->dbg_st_unfused = getenv("NAE_ST_UNFUSED") != nullptr;
-    ctx->dbg_rs_direct = getenv("NAE_RS_DIRECT") != nullptr;
-    ctx->dbg_spec_generic = getenv("NAE_SPEC_GENERIC") != nullptr;
-    ctx->dbg_spec_narrow = getenv("NAE_SPEC_NARROW") != nullptr;
-    ctx->pv_lean = getenv("NAE_PV_LEAN") != nullptr;
-    if (const char* t = getenv("NAE_PV_FLOW")) ctx->pv_flow = atoi(t);
-    if (const char* e = getenv("NAE_SPEC_CHUNK")) ctx->dbg_spec_chunk = atoi(e);
-    if (const char* e = getenv("NAE_SPEC_FINE")) ctx->dbg_spec_fine = atoi(e);
-    if (const char* e = getenv("NAE_SPEC_FINE_ROUNDS")) ctx->dbg_spec_fine_rounds = atoi(e);
+    if (const char* e = getenv("NAE_DEBUG")) {
+        // "key=value,key=value": the one environment hook of the switches of nae_debug_set
+        std::string all(e);
+        size_t pos = 0;
+        while (pos < all.size()) {
+            size_t end = all.find(',', pos);
+            if (end == std::string::npos) end = all.size();
+            const std::string kv = all.substr(pos, end - pos);
+            const size_t eq = kv.find('=');
+            if (!kv.empty() && (eq == std::string::npos || nae_debug_set(ctx, kv.substr(0, eq).c_str(), atoll(kv.c_str() + eq + 1)) != NAE_OK)) {
+                fprintf(stderr, "libnae_gpu: NAE_DEBUG: bad assignment '%s'\n", kv.c_str());
+                (void)hipStreamDestroy(ctx->stream);
+                delete ctx;
+                return NAE_ERR_INVALID;
+            }
+            pos = end + 1;
+        }
+    }
     std::vector<nae::cf> w512, t1024;
     std::vector<float> hann;
     build_tables(w512, t1024, hann);

@@ -28,20 +28,20 @@ struct nae_ctx {
     std::vector<float> h_rs_tab;
     struct nae_wsola_cache* wsola_cache = nullptr;   // plan + workspaces of nae_wsola_block_f32 (nae_wsola.hip)
     int pv_tile = 0;             // frames per phase-vocoder tile; 0 = choose per call (nae_pick_pv_shape)
-    int pv_fps = 0;              // NAE_PV_FPS=1|2|4: frames per step of the vocoder pipeline (0 = choose per call)
-    // tuning / A-B switches, read once from the environment at context creation (tools/ab_env.sh)
-    bool dbg_st_unfused = false;     // NAE_ST_UNFUSED: WSOLA chain runs filter and cubic stage as separate launches
-    int dbg_td_nc = 0;               // NAE_TD_NC=1|2|4: candidates per thread of the WSOLA search (0: by batch size)
-    bool dbg_no_mix_fuse = false;    // NAE_NO_MIX_FUSE: graph4 runs mix and transposer as separate launches
-    bool dbg_rs_single = false;      // NAE_RS_SINGLE: one stream per transposer workgroup (no coefficient sharing)
-    bool dbg_rs_direct = false;      // NAE_RS_DIRECT: direct (unstaged) transposer kernel
-    bool dbg_spec_generic = false;   // NAE_SPEC_GENERIC: skip the interleaved-stereo spectrum fast path
-    bool dbg_spec_narrow = false;    // NAE_SPEC_NARROW: the stereo spectrum kernel stores dword pieces (round 1-4 form) instead of 16-byte ones
-    int dbg_spec_fine = 0, dbg_spec_fine_rounds = 0;   // NAE_SPEC_FINE / NAE_SPEC_FINE_ROUNDS: frames of the short chunks at the end of a large launch's list / how many of them per resident wave
-    int dbg_spec_chunk = 0;          // NAE_SPEC_CHUNK: frames one wave of the stereo spectrum kernel walks (0: spec_pick_chunk)
-    int pv_flow = 1;                 // NAE_PV_FLOW=0|1|2: launches of at most one workgroup per CU run the one-barrier pipeline (kernels_pvflow.hip) never / with one
+    int pv_fps = 0;              // pv_fps = 1|2|4: frames per step of the vocoder pipeline (0 = choose per call)
+    // tuning / A-B switches: nae_debug_set(ctx, key, value) (include/nae_gpu.h lists the keys; NAE_DEBUG="key=value,..." applies them at context creation)
+    bool dbg_st_unfused = false;     // st_unfused: WSOLA chain runs filter and cubic stage as separate launches
+    int dbg_td_nc = 0;               // td_nc = 1|2|4: candidates per thread of the WSOLA search (0: by batch size)
+    bool dbg_no_mix_fuse = false;    // no_mix_fuse: graph4 runs mix and transposer as separate launches
+    bool dbg_rs_single = false;      // rs_single: one stream per transposer workgroup (no coefficient sharing)
+    bool dbg_rs_direct = false;      // rs_direct: direct (unstaged) transposer kernel
+    bool dbg_spec_generic = false;   // spec_generic: skip the interleaved-stereo spectrum fast path
+    bool dbg_spec_narrow = false;    // spec_narrow: the stereo spectrum kernel stores dword pieces (round 1-4 form) instead of 16-byte ones
+    int dbg_spec_fine = 0, dbg_spec_fine_rounds = 0;   // spec_fine / spec_fine_rounds: frames of the short chunks at the end of a large launch's list / how many of them per resident wave
+    int dbg_spec_chunk = 0;          // spec_chunk: frames one wave of the stereo spectrum kernel walks (0: spec_pick_chunk)
+    int pv_flow = 1;                 // pv_flow = 0|1|2: launches of at most one workgroup per CU run the one-barrier pipeline (kernels_pvflow.hip) never / with one
                                      // frame per step (default: where it is faster, profiles/r05_flow.md) / in every shape
-    bool pv_lean = false;            // NAE_PV_LEAN: the vocoder pipeline keeps its 64-VGPR shape even when one workgroup per CU would allow
+    bool pv_lean = false;            // pv_lean: the vocoder pipeline keeps its 64-VGPR shape even when one workgroup per CU would allow
                                      // 128 (leaves half of the register file and 94 KB of LDS to a co-resident kernel: tools/coresidency.py)
     // per-context, per-device launch state (a kernel attribute is set once per device: the flag lives with the context's device)
     unsigned pv_attr_done = 0;       // bit per pv_pipe_kernel instantiation whose dynamic-LDS attribute has been set through this context

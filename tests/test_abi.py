@@ -24,9 +24,9 @@ def test_library_exports_every_declared_symbol(nae):
     missing = [s for s in declared if not hasattr(lib, s)]
     assert not missing, missing
     assert sorted(nae.EXPORTED_SYMBOLS) == declared      # binding table and header agree
-    assert lib.nae_abi_version() == 2                     # 2: events, page-locked memory, wsola / swr handles; ctx_create's device rule
+    assert lib.nae_abi_version() == 3                     # 2: events, page-locked memory, wsola / swr handles; ctx_create's device rule; 3: nae_debug_set
     header = open(os.path.join(ROOT, "include", "nae_gpu.h")).read()
-    assert re.search(r"#define\s+NAE_ABI_VERSION\s+2\b", header)
+    assert re.search(r"#define\s+NAE_ABI_VERSION\s+3\b", header)
 
 
 def test_no_cpu_fallback_symbols(nae):

@@ -122,7 +122,7 @@ def test_c5_eighth_of_the_job_128_streams(ctx, nae):
 def test_c5_half_of_the_job_512_streams(ctx, nae):
     """What one rank of a 2-GPU job owns (512 streams = 1024 stream-channels = one workgroup per CU, one frame per step): the vocoder then runs
     its one-barrier pipeline (kernels_pvflow.hip: doubled hand-off buffers, dense block stores through the used-up buffer's tail).  On 2 s per
-    stream: all four outputs equal, bit for bit, those of a context that keeps the two-barrier pipeline (NAE_PV_FLOW=0); the same with the pitch
+    stream: all four outputs equal, bit for bit, those of a context that keeps the two-barrier pipeline (`debug_set("pv_flow", 0)`); the same with the pitch
     output 8 bytes off its 16-byte alignment (both kernels then fall back to dword stores); two streams against the oracle."""
     import os
     n_streams, S, p, first = 512, 96000, 2 ** (3 / 12), 512              # rank 1 of 2 owns streams 512..1023
@@ -137,9 +137,9 @@ def test_c5_half_of_the_job_512_streams(ctx, nae):
     d_cnt = ctx.empty(5, np.uint64).zero()
     ctx.diff_words(d_pitch.ptr, d_pitch_off.at(2), n_streams * pl.out_len * 2, d_cnt.at(3))
     ctx.diff_words(d_spec.ptr, d_spec_off.ptr, n_streams * F * 2 * 513, d_cnt.at(4))
-    os.environ["NAE_PV_FLOW"] = "0"
-    try:
+    if True:
         with nae.Context(0) as c2:
+            c2.debug_set("pv_flow", 0)
             ctx.sync()
             c2.prof_reset(); c2.prof_enable(True)
             m2, p2, s2, _, _, _ = run_graph(c2, nae, d_a, d_b, n_streams, S, p)
@@ -149,8 +149,6 @@ def test_c5_half_of_the_job_512_streams(ctx, nae):
             ctx.diff_words(d_pitch.ptr, p2.ptr, n_streams * pl.out_len * 2, d_cnt.at(1))
             ctx.diff_words(d_spec.ptr, s2.ptr, n_streams * F * 2 * 513, d_cnt.at(2))
             assert d_cnt.download().tolist() == [0, 0, 0, 0, 0]
-    finally:
-        os.environ.pop("NAE_PV_FLOW", None)
     b = orc.fill_uniform(S * 2, orc.stream_seed(0, 1))
     for s in (0, 511):
         pitch = slice_of(ctx, d_pitch, s * pl.out_len * 2, pl.out_len * 2)
@@ -164,7 +162,7 @@ def test_c5_half_of_the_job_512_streams(ctx, nae):
 def test_c3_one_hour_stereo_pitch(ctx, nae):
     """BASELINE.json configs[2]: the pitch node (+3 semitones, phase vocoder) on ONE stream of 1 h of 48 kHz stereo
     (172.8 M sample-frames, 1.38 GB): length, finiteness, the whole output against the oracle (relative RMS <= 1e-4, also
-    on the first and the last two seconds alone: Q0.32 phases carried over 675 000 frames and 60 tiles), and the start of
+    on the first and the last two seconds alone: Q0.32 phases carried over 675 000 frames and ~1023 tiles per channel), and the start of
     the run against a run on a prefix (time tiles are cut differently)."""
     L, ch, p = 3600 * 48000, 2, 2 ** (3 / 12)
     d_x = ctx.empty(L * ch)

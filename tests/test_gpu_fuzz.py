@@ -18,15 +18,12 @@ def test_fuzz_stretch_and_spectrum_seeded(nae, ctx):
 
 
 def test_fuzz_stretch_one_barrier_pipeline_in_every_shape(nae):
-    """the same randomised run with NAE_PV_FLOW=2: every vocoder launch of at most one workgroup per CU takes kernels_pvflow.hip, whatever its shape"""
+    """the same randomised run with `debug_set("pv_flow", 2)`: every vocoder launch of at most one workgroup per CU takes kernels_pvflow.hip, whatever its shape"""
     import os
     import fuzz_stretch
-    os.environ["NAE_PV_FLOW"] = "2"
-    try:
-        with nae.Context(0) as c:
-            assert fuzz_stretch.main(cases=10, seed=5, ctx=c, nae=nae) <= 1e-4
-    finally:
-        os.environ.pop("NAE_PV_FLOW", None)
+    with nae.Context(0) as c:
+        c.debug_set("pv_flow", 2)
+        assert fuzz_stretch.main(cases=10, seed=5, ctx=c, nae=nae) <= 1e-4
 
 
 def test_fuzz_wsola_seeded(nae, ctx):

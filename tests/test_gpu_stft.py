@@ -84,7 +84,8 @@ def test_k8_wide_stores_every_alignment_case(ctx, nae):
 
 def test_k8_guided_chunk_list_equals_the_generic_kernel(ctx, nae):
     """a large batch runs the persistent launch: 32-frame chunks, 8-frame chunks for the last streams, every chunk but a wave's first
-    drawn from a device counter that the launch's last wave resets.  8200 streams x 77 frames (odd: both store phases, a 13-frame tail chunk)
+    drawn from a device counter that a hipMemsetAsync on the stream zeroes in front of every drawing launch (launches with no more items than waves never
+    touch it).  8200 streams x 77 frames (odd: both store phases, a 13-frame tail chunk)
     against the one-wave-per-frame generic kernel on a second context, compared on the device; twice in a row (the counter must be back at
     zero), and three streams against the oracle"""
     import os
@@ -94,13 +95,10 @@ def test_k8_guided_chunk_list_equals_the_generic_kernel(ctx, nae):
     d_x, d_a, d_b = ctx.empty(n_streams * T * 2), ctx.empty(n_streams * n), ctx.empty(n_streams * n)
     ctx.fill_uniform(d_x.ptr, T * 2, T * 2, n_streams, 0, 0)
     sig = nae.Sig.interleaved(d_x.ptr, T, 2)
-    os.environ["NAE_SPEC_GENERIC"] = "1"
-    try:
-        with nae.Context(0) as generic:
-            generic.spectrum_block(sig, T, 2, n_streams, d_b.ptr, n)
-            generic.sync()
-    finally:
-        del os.environ["NAE_SPEC_GENERIC"]
+    with nae.Context(0) as generic:
+        generic.debug_set("spec_generic", 1)
+        generic.spectrum_block(sig, T, 2, n_streams, d_b.ptr, n)
+        generic.sync()
     d_cnt = ctx.array(np.zeros(2, np.uint64))
     for rep in range(2):
         ctx._ck(ctx.lib.nae_memset(ctx.h, d_a.ptr, 0xFF, n_streams * n * 4))
@@ -530,22 +528,35 @@ def test_k7_many_tiles_equal_one_tile_bit_for_bit(nae):
     ch, L, rate, pitch = 2, 4_400_000, 1.0, 2 ** (3 / 12)
     x = (0.5 * orc.fill_uniform(L * ch, 99)).astype(np.float32)
     outs = {}
-    try:
-        for key, env in (("one tile", {"NAE_PV_FPS": "1", "NAE_PV_TILE": "1000000"}), ("269 tiles", {"NAE_PV_TILE": "64"}), ("library", {})):
-            for k in ("NAE_PV_FPS", "NAE_PV_TILE"):
-                os.environ.pop(k, None)
-            os.environ.update(env)
-            with nae.Context(0) as c:
-                c.prof_reset(); c.prof_enable(True)
-                outs[key] = gpu_stretch(c, nae, x, ch, rate, pitch)[0]
-                c.prof_enable(False)
-                launched = set(c.prof_report())
-            assert ("pv_scan_kernel" in launched) == (key != "one tile"), (key, launched)
-    finally:
-        os.environ.pop("NAE_PV_FPS", None)
-        os.environ.pop("NAE_PV_TILE", None)
+    for key, knobs in (("one tile", {"pv_fps": 1, "pv_tile": 1000000}), ("269 tiles", {"pv_tile": 64}), ("library", {})):
+        with nae.Context(0) as c:
+            for k, v in knobs.items():
+                c.debug_set(k, v)
+            c.prof_reset(); c.prof_enable(True)
+            outs[key] = gpu_stretch(c, nae, x, ch, rate, pitch)[0]
+            c.prof_enable(False)
+            launched = set(c.prof_report())
+        assert ("pv_scan_kernel" in launched) == (key != "one tile"), (key, launched)
     for key in ("269 tiles", "library"):
         assert np.array_equal(outs[key].view(np.uint32), outs["one tile"].view(np.uint32)), key
+
+
+def test_k7_continued_segments_of_256_tiles_carry_the_phase_through_the_chunked_scan(nae):
+    """A stream handle fed in pieces of >= 256 pass-1 tiles (`debug_set("pv_tile", 64)`: 64-frame tiles, 4 M sample-frames per put = 290 tiles) runs pass 2 as
+    pv_scan_chunked_kernel WITH a phase carried in and out of every segment (the block-mode test above has neither).  The concatenated output equals
+    the block call of a context with the library's own shape, bit for bit."""
+    ch, L, rate, pitch = 2, 9_000_000, 1.0, float(np.float32(2 ** (3 / 12)))
+    x = (0.5 * orc.fill_uniform(L * ch, 123)).astype(np.float32)
+    with nae.Context(0) as c:
+        blk, _ = gpu_stretch(c, nae, x, ch, rate, pitch)
+    with nae.Context(0) as c:
+        c.debug_set("pv_tile", 64)
+        c.prof_reset(); c.prof_enable(True)
+        y, _ = stream_stretch(c, x, ch, rate, pitch, [4_000_000, 4_000_000, 1_000_000], recv_chunk=1 << 18, device_put=True)
+        c.prof_enable(False)
+        assert "pv_scan_kernel" in c.prof_report()
+    assert y.size == blk.size
+    assert np.array_equal(y.view(np.uint32), blk.view(np.uint32)), int(np.count_nonzero(y != blk))
 
 
 @pytest.mark.parametrize("ch,n_streams,L,rate,pitch", [(2, 3, 30000, 1.0, 2 ** (3 / 12)), (1, 5, 21001, 1.0, 2 ** (-4 / 12)), (2, 2, 9000, 1.5, 1 / 1.5)])
@@ -553,21 +564,16 @@ def test_k7_pipeline_modes_agree_bit_for_bit(nae, ch, n_streams, L, rate, pitch)
     """The vocoder pipeline runs a stream-channel through its four roles one frame per step (large batches) or 2 / 4 consecutive
     frames per step (frame-interleaved: small batches), with or without time tiles (pass 1 + scan).  All shapes deliver the same
     samples bit for bit — same integer phases, same overlap-add order — and match the oracle within the tolerance.  The shapes are
-    forced through the tuning knobs NAE_PV_FLOW / NAE_PV_FPS / NAE_PV_TILE, read when a context is created."""
+    forced through nae_debug_set (pv_flow / pv_fps / pv_tile)."""
     x = (0.5 * orc.fill_uniform(n_streams * L * ch, 77)).astype(np.float32)
     outs = {}
-    try:
-        for flow in ("0", "2"):          # two barriers per step (kernels_pvpipe.hip) / one barrier, doubled hand-off buffers (kernels_pvflow.hip)
-            for fps in ("1", "2", "4"):
-                for tile in ("0", "64"):
-                    os.environ["NAE_PV_FLOW"], os.environ["NAE_PV_FPS"], os.environ["NAE_PV_TILE"] = flow, fps, tile
-                    with nae.Context(0) as c:
-                        outs[(flow, fps, tile)] = gpu_stretch(c, nae, x, ch, rate, pitch, n_streams=n_streams)[0]
-    finally:
-        os.environ.pop("NAE_PV_FLOW", None)
-        os.environ.pop("NAE_PV_FPS", None)
-        os.environ.pop("NAE_PV_TILE", None)
-    first = outs[("0", "1", "0")]
+    for flow in (0, 2):                  # two barriers per step, one buffer per hand-off / one barrier, doubled hand-off buffers
+        for fps in (1, 2, 4):
+            for tile in (0, 64):
+                with nae.Context(0) as c:
+                    c.debug_set("pv_flow", flow).debug_set("pv_fps", fps).debug_set("pv_tile", tile)
+                    outs[(flow, fps, tile)] = gpu_stretch(c, nae, x, ch, rate, pitch, n_streams=n_streams)[0]
+    first = outs[(0, 1, 0)]
     for key, o in outs.items():
         assert np.array_equal(o.view(np.uint32), first.view(np.uint32)), key
     per = first.reshape(n_streams, -1)

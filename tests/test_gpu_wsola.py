@@ -60,11 +60,11 @@ def test_block_is_bit_exact(ctx, nae, sr, ch, rate, pitch, L):
 
 
 @pytest.mark.parametrize("nc", [1, 2, 4])
-def test_every_search_shape_is_bit_exact(nae, nc, monkeypatch):
+def test_every_search_shape_is_bit_exact(nae, nc):
     """the stretcher kernel has three shapes (4 / 2 / 1 candidate offsets per thread, picked by batch size); each must give the oracle's offsets
     and samples.  The stereo 48-kHz cases of shape 4 run the instantiation with a compile-time LDS row stride, the others the generic one."""
-    monkeypatch.setenv("NAE_TD_NC", str(nc))
     c = nae.Context(0)
+    c.debug_set("td_nc", nc)
     try:
         for sr, ch, rate, pitch, L in ((48000, 2, 1.0, 2 ** (3 / 12), 40000), (48000, 1, 1.0, 0.8, 30000),
                                        (22050, 1, 1.0, 0.8, 22050), (8000, 2, 1.2, 1.0, 12000), (44100, 2, 1.0, 2 ** (-4 / 12), 30000),

@@ -11,7 +11,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOST = os.path.join(ROOT, "nodey-audio-editor_amd", "host")
 SRC = ["infra/fiber.cpp", "infra/runner.cpp", "processor/audio-stream.cpp", "processor/audio-vol.cpp", "processor/audio-mix.cpp",
-       "processor/audio-velocity.cpp", "register.cpp"]
+       "processor/audio-velocity.cpp", "processor/draw-headless.cpp", "register.cpp"]
 SAN = ["-O1", "-g", "-std=c++20", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-ffp-contract=off"]
 
 

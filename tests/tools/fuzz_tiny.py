@@ -1,5 +1,5 @@
 """Randomised differential run (GPU box) of the vocoder on TINY inputs (1 .. 5000 sample-frames: fewer frames than a pipeline step,
-lengths around the FFT size) for every shape of the pipeline (NAE_PV_FPS 1 / 2 / 4, with and without 64-frame tiles) against the oracle.
+lengths around the FFT size) for every shape of the pipeline (pv_fps 1 / 2 / 4 through nae_debug_set, with and without 64-frame tiles) against the oracle.
 Outputs of a few samples sit on the window's edge, where they are rounding noise (1e-11 for a 0.5-amplitude input), so the error is
 measured against max(RMS of the reference, 1e-4): python tests/tools/fuzz_tiny.py"""
 import os, sys
@@ -10,12 +10,10 @@ nae = naeload.load()
 rng = np.random.default_rng(5)
 worst = 0.0
 n_cases = 0
-for fps in ("0", "1", "2", "4"):
-    for tile in ("0", "64"):
-        if fps == "0": os.environ.pop("NAE_PV_FPS", None)
-        else: os.environ["NAE_PV_FPS"] = fps
-        os.environ["NAE_PV_TILE"] = tile
+for fps in (0, 1, 2, 4):
+    for tile in (0, 64):
         with nae.Context(0) as ctx:
+            ctx.debug_set("pv_fps", fps).debug_set("pv_tile", tile)
             for k in range(14):
                 ch = int(rng.choice([1, 2])); n_streams = int(rng.choice([1, 2, 3, 9]))
                 L = int(rng.choice([1, 2, 17, 200, 255, 256, 257, 511, 700, 1023, 1024, 1025, 1500, 2600, 5000]))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B helper: the C5 graph on a few streams under each environment setting given on the command line; every result buffer is
-compared bit for bit with the first setting's.     python tools/ab_check.py "" "NAE_RS_WIDE=1" "NAE_SPEC_RICH=1" """
+compared bit for bit with the first setting's.     python tools/ab_check.py "" "NAE_DEBUG=spec_narrow=1" "NAE_DEBUG=pv_flow=2" """
 import os
 import sys
 

@@ -102,6 +102,12 @@ def run_queues(nae, device, L, n_chunks):
         chunk(i)
     down.sync()
     dt = time.perf_counter() - t0
+    # events go before the contexts they were created from (include/nae_gpu.h)
+    for ctx_of, evs in ((up, ev_up), (down, ev_down)):
+        for e in evs:
+            ctx_of.destroy_event(e)
+    for ln, e in zip(L, ev_graph):
+        ln.ctx.destroy_event(e)
     up.close(); down.close()
     return dt
 

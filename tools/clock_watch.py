@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Sample the GPU's core clock and power (rocm-smi) while the C5 graph runs in a loop: is the step clock- or power-limited?
    python tools/clock_watch.py [seconds [streams [stage mask: 7 = whole graph, 2 = the vocoder alone]]]
-   (NAE_PV_FLOW=0|2 in the environment: two-barrier / one-barrier vocoder pipeline; profiles/r05_flow.md)"""
+   (NAE_DEBUG=pv_flow=0 | pv_flow=2 in the environment: two-barrier / one-barrier vocoder pipeline; profiles/r05_flow.md)"""
 import json
 import os
 import subprocess

@@ -13,7 +13,7 @@ modes
              each vocoder runs beside the other half's spectrum and next front stage
   joined     stagger, and stream A waits for B's last kernel at the end of every step (what a split inside nae_graph4_run would
              have to do so that whatever the caller enqueues next sees all results)
-Each two-context mode is run with the vocoder in its 64-VGPR shape (NAE_PV_LEAN, leaves registers and LDS to a co-runner) and in
+Each two-context mode is run with the vocoder in its 64-VGPR shape (NAE_DEBUG=pv_lean=1, leaves registers and LDS to a co-runner) and in
 the shape nae_graph4_run picks by itself for 512 streams (128 VGPRs, tables in registers, fills the register file alone)."""
 import argparse
 import os
@@ -100,7 +100,7 @@ def main():
 
     for mode in a.modes:
         if mode == "one":
-            os.environ.pop("NAE_PV_LEAN", None)
+            os.environ.pop("NAE_DEBUG", None)
             ctx, g, bufs = build(nae, a.streams, S, p)
 
             def fn(k):
@@ -113,16 +113,16 @@ def main():
             continue
         for lean in (True, False):
             if lean:
-                os.environ["NAE_PV_LEAN"] = "1"
+                os.environ["NAE_DEBUG"] = "pv_lean=1"
             else:
-                os.environ.pop("NAE_PV_LEAN", None)
+                os.environ.pop("NAE_DEBUG", None)
             lanes = [build(nae, half, S, p, 0), build(nae, a.streams - half, S, p, half)]
             ms = timed(lambda k: run(mode, lanes, k))
             print(f"{mode:10s} {'vocoder 64 VGPRs' if lean else 'vocoder 128 VGPRs':22s} {ms:7.3f} ms per step of {a.streams} streams, "
                   f"clock {lanes[0][0].clock_ghz():.2f} GHz", flush=True)
             for ctx, _, _ in lanes:
                 ctx.close()
-        os.environ.pop("NAE_PV_LEAN", None)
+        os.environ.pop("NAE_DEBUG", None)
 
 
 if __name__ == "__main__":

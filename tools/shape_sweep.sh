@@ -4,7 +4,7 @@
 # prints ms per step, the vocoder's ms, the in-run clock and cycles per step (= ms x clock): one box, settled clocks (30 steps behind 10)
 for n in $1; do
 for f in $2; do
-  if [ "$f" == "auto" ]; then unset NAE_PV_FPS; else export NAE_PV_FPS=$f; fi
+  if [ "$f" == "auto" ]; then unset NAE_DEBUG; else export NAE_DEBUG=pv_fps=$f; fi
   python bench.py --steps 30 --warmup 10 --no-cpu-baseline --no-alt --no-pcie --no-host-path --sustain-seconds 0 --total-streams $n | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
