@@ -149,7 +149,7 @@ int nae_ensure_rs_table(nae_ctx* ctx, double rate_eff)
 // Shape of the phase vocoder for a block call: frames per step of the pipeline (kernels_pvpipe.hip), synthesis tile, pass-1 tile.
 //   * more than 3 stream-channels per CU (>= 1024 at 256 CUs, e.g. 512 stereo streams): four stream-channels per workgroup
 //     (frames_per_step 1), ONE tile per stream-channel — no pass 1, nothing analysed twice; from 2048 stream-channels two
-//     workgroups share a CU; up to 1024 stream-channels (one workgroup per CU) the launch runs the one-barrier build, kernels_pvflow.hip.
+//     workgroups share a CU; up to 1024 stream-channels (one workgroup per CU) the launch runs the one-barrier schedule (pv_flow_kernel).
 //     (2 to 3 per CU: the frame-interleaved shape below in three rounds, see the code.)
 //   * fewer: the four slots of a workgroup work on 2 or 4 consecutive frames of one stream-channel (frame-interleaved), so
 //     256 stream-channels (the 128 streams one rank of an 8-GPU job owns) still give every CU a workgroup without cutting
@@ -189,17 +189,21 @@ int nae_pick_pv_shape(nae_ctx* ctx, size_t frames, size_t n_sc, int* phase_tile,
             return (int)(3 * third);
         }
     }
-    const size_t max_tiles = (frames + 63) / 64;
+    // a synthesis tile pays 4 priming / tail frames and keeps >= 64; a pass-1 tile pays one priming frame and may be as short as kMinPhase frames, so that
+    // pass 1 still gets its 24 n_cu waves on short streams (40 streams of 10 s: 6160 waves of 29 frames instead of 2800 of 64: profiles/r06_pass1.md)
+    const size_t kMinPhase = ctx->dbg_pv_min_ptile > 0 ? (size_t)ctx->dbg_pv_min_ptile : 16;
+    const size_t max_synth = (frames + 63) / 64, max_phase = (frames + kMinPhase - 1) / kMinPhase;
     // workgroups wanted: one per CU (two from 2048 stream-channels, where no tiles are needed anyway)
     const size_t wg = (n_sc * (size_t)fps + 3) / 4;                      // workgroups of one tile per stream-channel
     size_t n_synth = wg >= n_cu ? 1 : n_cu / wg;
-    if (n_synth > max_tiles) n_synth = max_tiles;
+    if (n_synth > max_synth) n_synth = max_synth;
     size_t n_phase = n_synth == 1 ? 1 : (24 * n_cu + n_sc - 1) / n_sc;   // a single synthesis tile needs no pass 1; else six waves per SIMD
-    if (n_phase > max_tiles) n_phase = max_tiles;
+    if (n_phase > max_phase) n_phase = max_phase;
     size_t step = (n_phase + n_synth - 1) / n_synth;
     if (step < 1) step = 1;
     size_t pt = (frames + n_synth * step - 1) / (n_synth * step);
-    if (pt < 64) pt = 64;
+    if (pt < kMinPhase) pt = kMinPhase;
+    if (pt * step < 64) pt = (64 + step - 1) / step;
     *phase_tile = (int)pt;
     return (int)(pt * step);
 }
@@ -232,6 +236,7 @@ int nae_debug_set(nae_ctx* ctx, const char* key, long long value)
     else if (k == "pv_fps" && one_of({0, 1, 2, 4})) ctx->pv_fps = (int)value;
     else if (k == "pv_flow" && one_of({0, 1, 2})) ctx->pv_flow = (int)value;
     else if (k == "pv_lean" && flag) ctx->pv_lean = value != 0;
+    else if (k == "pv_min_ptile" && count) ctx->dbg_pv_min_ptile = (int)value;
     else if (k == "rs_single" && flag) ctx->dbg_rs_single = value != 0;
     else if (k == "rs_direct" && flag) ctx->dbg_rs_direct = value != 0;
     else if (k == "no_mix_fuse" && flag) ctx->dbg_no_mix_fuse = value != 0;

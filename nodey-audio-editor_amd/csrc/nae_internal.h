@@ -39,7 +39,8 @@ struct nae_ctx {
     bool dbg_spec_narrow = false;    // spec_narrow: the stereo spectrum kernel stores dword pieces (round 1-4 form) instead of 16-byte ones
     int dbg_spec_fine = 0, dbg_spec_fine_rounds = 0;   // spec_fine / spec_fine_rounds: frames of the short chunks at the end of a large launch's list / how many of them per resident wave
     int dbg_spec_chunk = 0;          // spec_chunk: frames one wave of the stereo spectrum kernel walks (0: spec_pick_chunk)
-    int pv_flow = 1;                 // pv_flow = 0|1|2: launches of at most one workgroup per CU run the one-barrier pipeline (kernels_pvflow.hip) never / with one
+    int dbg_pv_min_ptile = 0;        // pv_min_ptile: shortest pass-1 tile in frames (0: 16)
+    int pv_flow = 1;                 // pv_flow = 0|1|2: launches of at most one workgroup per CU run the one-barrier schedule (pv_flow_kernel) never / with one
                                      // frame per step (default: where it is faster, profiles/r05_flow.md) / in every shape
     bool pv_lean = false;            // pv_lean: the vocoder pipeline keeps its 64-VGPR shape even when one workgroup per CU would allow
                                      // 128 (leaves half of the register file and 94 KB of LDS to a co-resident kernel: tools/coresidency.py)

@@ -69,5 +69,3 @@ __device__ __forceinline__ void phase_inc(const uint32_t (&qa)[9], const uint32_
 // kernels_pvpipe.hip
 int nae_launch_pv_pipe(nae_ctx* ctx, const nae::PvParams& p, const nae::SigViewD& src, long long n_sc, const uint32_t* phase_ws,
                        const nae::OutViewD& out, bool unit_stride, int frames_per_step);
-int nae_launch_pv_flow(nae_ctx* ctx, const nae::PvParams& p, const nae::SigViewD& src, long long n_sc, const uint32_t* phase_ws,
-                       const nae::OutViewD& out, bool unit_stride, int frames_per_step);

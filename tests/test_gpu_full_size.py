@@ -121,7 +121,7 @@ def test_c5_eighth_of_the_job_128_streams(ctx, nae):
 
 def test_c5_half_of_the_job_512_streams(ctx, nae):
     """What one rank of a 2-GPU job owns (512 streams = 1024 stream-channels = one workgroup per CU, one frame per step): the vocoder then runs
-    its one-barrier pipeline (kernels_pvflow.hip: doubled hand-off buffers, dense block stores through the used-up buffer's tail).  On 2 s per
+    its one-barrier pipeline (pv_flow_kernel: doubled hand-off buffers, dense block stores through the used-up buffer's tail).  On 2 s per
     stream: all four outputs equal, bit for bit, those of a context that keeps the two-barrier pipeline (`debug_set("pv_flow", 0)`); the same with the pitch
     output 8 bytes off its 16-byte alignment (both kernels then fall back to dword stores); two streams against the oracle."""
     import os

@@ -18,7 +18,7 @@ def test_fuzz_stretch_and_spectrum_seeded(nae, ctx):
 
 
 def test_fuzz_stretch_one_barrier_pipeline_in_every_shape(nae):
-    """the same randomised run with `debug_set("pv_flow", 2)`: every vocoder launch of at most one workgroup per CU takes kernels_pvflow.hip, whatever its shape"""
+    """the same randomised run with `debug_set("pv_flow", 2)`: every vocoder launch of at most one workgroup per CU takes the one-barrier schedule (pv_flow_kernel), whatever its shape"""
     import os
     import fuzz_stretch
     with nae.Context(0) as c:

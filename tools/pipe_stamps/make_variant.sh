@@ -25,5 +25,5 @@ for f in nae_api nae_stream nae_swr kernels_nodes nae_wsola; do /opt/rocm/bin/hi
 /opt/rocm/bin/hipcc $COMMON -fno-slp-vectorize -c $D/csrc/kernels_wsola.hip -o /tmp/s_kernels_wsola.o 2>/dev/null &
 wait
 rm -f $SRC
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/variants/libnae_gpu_stamps.so /tmp/s_nae_api.o /tmp/s_nae_stream.o /tmp/s_nae_swr.o /tmp/s_kernels_nodes.o /tmp/s_kernels_stft.o /tmp/s_kernels_pvpipe.o /root/repo/nodey-audio-editor_amd/csrc/kernels_pvflow.o /tmp/s_nae_wsola.o /tmp/s_kernels_wsola.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/variants/libnae_gpu_stamps.so /tmp/s_nae_api.o /tmp/s_nae_stream.o /tmp/s_nae_swr.o /tmp/s_kernels_nodes.o /tmp/s_kernels_stft.o /tmp/s_kernels_pvpipe.o /tmp/s_nae_wsola.o /tmp/s_kernels_wsola.o
 echo built $D/variants/libnae_gpu_stamps.so
