@@ -222,8 +222,8 @@ class Context:
         h = C.c_void_p()
         rc = self.lib.nae_ctx_create(device, C.byref(h))
         if rc != 0:
-            raise NaeError(f"nae_ctx_create(device={device}) failed with {rc}: no usable HIP device — "
-                           "this library has no CPU fallback")
+            why = ("no such device, or a bad assignment in $NAE_DEBUG" if rc == -1 else "no usable HIP device")
+            raise NaeError(f"nae_ctx_create(device={device}) failed with {rc}: {why} — this library has no CPU fallback")
         self.h = h
         self.device = device
         self._allocs = set()

@@ -159,3 +159,24 @@ def test_two_devices_when_the_box_has_them(nae):
     finally:
         a.close()
         b.close()
+
+
+@pytest.mark.gpu
+def test_debug_set_rejects_unknown_keys_and_the_environment_form_applies_at_creation(nae):
+    """nae_debug_set is the one entry point of the tuning switches (include/nae_gpu.h): an unknown key or a value out of range is NAE_ERR_INVALID and changes
+    nothing; NAE_DEBUG="k=v,k=v" applies the same assignments when a context is created, and a bad assignment there fails the creation"""
+    import os
+    with nae.Context(0) as c:
+        c.debug_set("pv_flow", 2).debug_set("pv_fps", 4).debug_set("pv_tile", 64).debug_set("pv_min_ptile", 32)
+        for key, value in (("no_such_switch", 1), ("pv_fps", 3), ("pv_flow", 7), ("pv_lean", 2), ("pv_tile", -1)):
+            with pytest.raises(nae.NaeError):
+                c.debug_set(key, value)
+    try:
+        os.environ["NAE_DEBUG"] = "pv_flow=0,spec_generic=1"
+        with nae.Context(0):
+            pass
+        os.environ["NAE_DEBUG"] = "pv_flow=0,bogus=1"
+        with pytest.raises(nae.NaeError):
+            nae.Context(0)
+    finally:
+        os.environ.pop("NAE_DEBUG", None)

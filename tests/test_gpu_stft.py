@@ -528,7 +528,8 @@ def test_k7_many_tiles_equal_one_tile_bit_for_bit(nae):
     ch, L, rate, pitch = 2, 4_400_000, 1.0, 2 ** (3 / 12)
     x = (0.5 * orc.fill_uniform(L * ch, 99)).astype(np.float32)
     outs = {}
-    for key, knobs in (("one tile", {"pv_fps": 1, "pv_tile": 1000000}), ("269 tiles", {"pv_tile": 64}), ("library", {})):
+    for key, knobs in (("one tile", {"pv_fps": 1, "pv_tile": 1000000}), ("269 tiles", {"pv_tile": 64}), ("library", {}), ("pass-1 tiles >= 64", {"pv_min_ptile": 64}),
+                       ("frame-interleaved + tiles", {"pv_fps": 4}), ("16-frame tiles", {"pv_tile": 16})):
         with nae.Context(0) as c:
             for k, v in knobs.items():
                 c.debug_set(k, v)
@@ -537,7 +538,7 @@ def test_k7_many_tiles_equal_one_tile_bit_for_bit(nae):
             c.prof_enable(False)
             launched = set(c.prof_report())
         assert ("pv_scan_kernel" in launched) == (key != "one tile"), (key, launched)
-    for key in ("269 tiles", "library"):
+    for key in outs:
         assert np.array_equal(outs[key].view(np.uint32), outs["one tile"].view(np.uint32)), key
 
 

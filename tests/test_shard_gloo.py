@@ -131,3 +131,28 @@ def test_bench_self_launch_reports_a_failing_child_plainly():
     env.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True, env=env, timeout=120)
     assert r.returncode != 0 and "launched as 1 rank(s) for --gpus 2" in r.stderr and r.stdout.strip() == ""
+
+
+def test_bench_counts_the_cores_it_may_really_use(tmp_path, monkeypatch):
+    """`cpu_baseline.all_workers` runs on every core the process may use: the affinity mask, cut by a cgroup CPU quota — on the
+    GPU boxes of this pool the mask shows the host's 256 CPUs while the quota is 16"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cores, info = bench.usable_cores()
+    assert 1 <= cores <= info["affinity"] <= (os.cpu_count() or 1)
+    if info["cgroup_cpu_quota"] is not None:
+        assert cores == max(1, min(info["affinity"], int(info["cgroup_cpu_quota"] + 0.5)))
+    real_open = open
+
+    def fake_open(path, *a, **k):
+        if path == "/sys/fs/cgroup/cpu.max":
+            f = tmp_path / "cpu.max"
+            f.write_text("200000 100000\n")
+            return real_open(f, *a, **k)
+        return real_open(path, *a, **k)
+
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(64)), raising=False)
+    monkeypatch.setattr("builtins.open", fake_open)
+    assert bench.usable_cores()[0] == 2
