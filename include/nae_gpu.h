@@ -118,7 +118,7 @@ int nae_debug_clock_ghz(nae_ctx* ctx, double* ghz);
 
 /* Tuning / A-B switches of one context (tests and measurement tools; the defaults are the product).  Takes effect from the next call on.
  * Unknown key or value out of range: NAE_ERR_INVALID.  Keys (value 0 = the library's own choice unless said otherwise):
- *   pv_tile         frames per phase-vocoder time tile (pass 1 and pass 3)
+ *   pv_tile         frames per phase-vocoder time tile (pass 1 and pass 3);  pv_min_ptile  shortest pass-1 tile the library may choose (default 16)
  *   pv_fps          1 | 2 | 4: frames per step of the vocoder pipeline
  *   pv_flow         0 | 1 | 2: launches of at most one workgroup per CU run the one-barrier schedule never / with one frame per step (default 1) / always
  *   pv_lean         1: the pipeline keeps its 64-VGPR two-workgroups-per-CU build even when one workgroup per CU would allow 128
