@@ -82,6 +82,8 @@ __global__ __launch_bounds__(kThreads, 4) void spectrum_kernel(SigViewD src, lon
 // that bypass L2 allocation — they are never read again by this kernel — another 0.1-0.3 ms.)
 constexpr int kSpecChunk = 32;         // frames one wave walks when the launch has many rounds of waves (16 / 64 / 128 measured
                                        // within 1 %: profiles/r02_spectrum_ablation.md); small batches: spec_pick_chunk
+constexpr int kSpecChunkLarge = 16;    // frames per chunk of a large (persistent, chunk-drawing) launch: 12-16 measured 1.8 % faster than 32 at C5, 8 5 % slower
+                                       // (round 6, gpurun_out: 2.70-2.73 against 2.76-2.78 and 2.92 ms; a chunk's head re-reads 3/4 of a frame)
 constexpr int kSpecChunkFine = 8;      // frames of the short chunks at the end of a large launch's work list
 constexpr int kSpecStoreAux = 2;       // cache policy bits of the spectrum stores (2 = nt)
 constexpr size_t kLdsTablesPad = NAE_FFT_N * sizeof(float) + (kT1024Pad + 64 + kTwaCf) * sizeof(cf);
@@ -971,9 +973,9 @@ int nae_launch_spectrum(nae_ctx* ctx, const nae_sig* src, size_t T, int ch, size
             w.chunk_f = w.chunk_c;
             w.cps_f = w.cps_c;
         } else {
-            // large batch: 32-frame chunks, and 8-frame chunks for the last streams — about four short chunks per resident wave, at most an
+            // large batch: 16-frame chunks, and 8-frame chunks for the last streams — about four short chunks per resident wave, at most an
             // eighth of the job — so that the launch ends within one short chunk
-            w.chunk_c = ctx->dbg_spec_chunk > 0 ? ctx->dbg_spec_chunk : kSpecChunk;
+            w.chunk_c = ctx->dbg_spec_chunk > 0 ? ctx->dbg_spec_chunk : kSpecChunkLarge;
             w.cps_c = (unsigned)(((long long)F + w.chunk_c - 1) / w.chunk_c);
             w.chunk_f = ctx->dbg_spec_fine > 0 ? ctx->dbg_spec_fine : kSpecChunkFine;
             w.cps_f = (unsigned)(((long long)F + w.chunk_f - 1) / w.chunk_f);

@@ -83,7 +83,7 @@ def test_k8_wide_stores_every_alignment_case(ctx, nae):
 
 
 def test_k8_guided_chunk_list_equals_the_generic_kernel(ctx, nae):
-    """a large batch runs the persistent launch: 32-frame chunks, 8-frame chunks for the last streams, every chunk but a wave's first
+    """a large batch runs the persistent launch: 16-frame chunks, 8-frame chunks for the last streams, every chunk but a wave's first
     drawn from a device counter that a hipMemsetAsync on the stream zeroes in front of every drawing launch (launches with no more items than waves never
     touch it).  8200 streams x 77 frames (odd: both store phases, a 13-frame tail chunk)
     against the one-wave-per-frame generic kernel on a second context, compared on the device; twice in a row (the counter must be back at
